@@ -1,0 +1,229 @@
+/*
+ * l2hmc_hip.h -- C ABI of libl2hmc_hip.so: the MI355X (gfx950) implementation
+ * of the L2HMC augmented-leapfrog hot path of saforem2/l2hmc.
+ *
+ * Drop-in boundary.  The reference is pure Python on TensorFlow 1.x; its "FFI"
+ * for this path is the set of TF graph ops its Dynamics classes emit.  Each
+ * entry point below replaces the ops of the reference function cited next to
+ * it (paths relative to the reference checkout, `l2hmc/...`).  The Python host
+ * classes in l2hmc_amd/ (GaugeDynamics, Dynamics, propose, ...) bind these via
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (int32 where said);
+ *     rows are chains (or chain x direction pairs), row-major [rows][D];
+ *   - nothing allocates, frees or synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream); scratch
+ *     comes from the caller through (ws, ws_bytes), sized by the *_ws_bytes
+ *     queries, so calls are hipGraph-capturable;
+ *   - inputs are never written; outputs never alias inputs unless documented;
+ *   - return value: L2HMC_OK or an error code; l2hmc_last_error() gives text.
+ *     Shape/argument violations are rejected on the host before any launch;
+ *   - randomness is always an input buffer (l2hmc_fill_* produce them), so a
+ *     caller can replay the reference's draws;
+ *   - direction codes: 0 = forward (_forward_lf), 1 = backward (_backward_lf).
+ */
+#ifndef L2HMC_HIP_H
+#define L2HMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2HMC_OK 0
+#define L2HMC_ERR_ARG 1       /* bad shape / null pointer / unsupported size */
+#define L2HMC_ERR_HIP 2       /* a HIP runtime call or launch failed */
+#define L2HMC_ERR_WORKSPACE 3 /* workspace too small */
+
+#define L2HMC_ABI_VERSION 1
+
+typedef void* l2hmc_stream_t;
+
+int l2hmc_abi_version(void);
+const char* l2hmc_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * U(1) lattice: action, force, observables.
+ *   lattice/lattice.py:337-362 total_action; :285-313 calc_plaq_observables;
+ *   gauge_model.py:659-725 _calc_plaq_sums/_total_actions/_avg_plaqs/_top_charges;
+ *   dynamics/gauge_dynamics.py:698-709 grad_potential (autodiff of the action;
+ *   closed form in lattice/gauge_lattice.py:427-459).
+ * x: [rows][T][X][2].  Any output pointer may be NULL (skipped).
+ *   action[r]  = sum_ij (1 - cos P)          force[r][:] = beta * dS/dx
+ *   avg_plaq[r]= sum_ij cos P / (T*X)        top_charge[r] = sum_ij project(P) / 2pi
+ * ------------------------------------------------------------------------ */
+int l2hmc_u1_action_force(const float* x, int64_t rows, int32_t T, int32_t X, float beta,
+                          float* action, float* force, float* avg_plaq, float* top_charge,
+                          l2hmc_stream_t stream);
+
+/* gauge_model.py:659-681: plaq[r][i][j] = x0[i,j] - x1[i,j] - x0[i,j+1] + x1[i+1,j]. */
+int l2hmc_u1_plaq_sums(const float* x, int64_t rows, int32_t T, int32_t X, float* plaq,
+                       l2hmc_stream_t stream);
+
+/* gauge_dynamics.py:683-689 / utils/dynamics.py:112-113: out[r] = 0.5 * sum_d v^2. */
+int l2hmc_kinetic_energy(const float* v, int64_t rows, int32_t D, float* out, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Dense S/T/Q network (GenericNet / dense trunk of ConvNet3D / `network` MLP).
+ *   network/generic_net.py:129-146, network/conv_net.py:264-280,
+ *   utils/network.py:89-114.
+ * Weights are PACKED by the host (l2hmc_amd/network.py) from the reference's
+ * [in,out] Dense kernels into k-contiguous ("[out][in]") device buffers:
+ *   w1_t   [H][Ka+Kb]  rows of v_layer (first input, Ka cols) then x_layer (Kb)
+ *   wt     [2][H]      t_layer kernel            b1 [H] = b_v + b_x + b_t
+ *   wh_t   [H][H]      h_layer                   bh [H]
+ *   whd_t  [3][D][H]   scale / translation / transformation layers
+ *   bhd    [3][D]      their biases
+ *   coeff_s, coeff_q [D]  coeff_scale / coeff_transformation (exp applied on device)
+ *   q_tanh: 0 = GenericNet/ConvNet3D (no tanh on transformation, quirk Q1),
+ *           1 = utils/network.py `network` (ScaleTanh on F as well).
+ * ------------------------------------------------------------------------ */
+typedef struct l2hmc_dense_net {
+  int32_t D;   /* output width (x_dim) */
+  int32_t H;   /* hidden width */
+  int32_t Ka;  /* width of first input  (v_layer / embed_1) */
+  int32_t Kb;  /* width of second input (x_layer / embed_2) */
+  const float* w1_t;
+  const float* wt;
+  const float* b1;
+  const float* wh_t;
+  const float* bh;
+  const float* whd_t;
+  const float* bhd;
+  const float* coeff_s;
+  const float* coeff_q;
+  int32_t q_tanh;
+  int32_t reserved;
+} l2hmc_dense_net;
+
+/* scratch for one net evaluation on `rows` rows: two [rows][H] activations */
+size_t l2hmc_stq_ws_bytes(int64_t rows, int32_t H);
+
+/* (S, T, Q) = net([a, b * bmask, t])  with t = [t_cos, t_sin] for every row.
+ * a: [rows][Ka], b: [rows][Kb], bmask: [Kb] or NULL.  S, T, Q: [rows][D]. */
+int l2hmc_stq_dense(const l2hmc_dense_net* net, const float* a, const float* b, const float* bmask,
+                    float t_cos, float t_sin, int64_t rows, float* S, float* T, float* Q,
+                    void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Leapfrog sub-updates on materialised S/T/Q (standalone forms).
+ *   v: gauge_dynamics.py:486-508 (dir 0), :537-561 (dir 1)
+ *   x: gauge_dynamics.py:511-534 (dir 0), :565-590 (dir 1);
+ *      `keep` is the mask fed to the net (1 = element kept, 0 = updated).
+ * logdet[r] receives sum_d s (v) or sum_d (1-keep) s (x).  out may alias in.
+ * ------------------------------------------------------------------------ */
+int l2hmc_lf_update_v(const float* v, const float* grad, const float* S, const float* T,
+                      const float* Q, float eps, int32_t dir, int64_t rows, int32_t D,
+                      float* v_out, float* logdet, l2hmc_stream_t stream);
+int l2hmc_lf_update_x(const float* x, const float* v, const float* keep, const float* S,
+                      const float* T, const float* Q, float eps, int32_t dir, int64_t rows,
+                      int32_t D, float* x_out, float* logdet, l2hmc_stream_t stream);
+
+/* gauge_dynamics.py:592-609 / utils/dynamics.py:312-319:
+ * p = exp(min(h_old - h_new + sumlogdet, 0)), non-finite -> 0. */
+int l2hmc_accept_prob(const float* h_old, const float* h_new, const float* sumlogdet, int64_t n,
+                      float* p, l2hmc_stream_t stream);
+
+/* gauge_dynamics.py:221-257 (strict=1: accept iff p > u, forward iff coin > 0.5)
+ * utils/sampler.py:33-59    (strict=0: accept iff p - u >= 0, forward iff coin != 0).
+ * xf,vf,pf / xb,vb,pb: forward / backward trajectories of the same B chains. */
+int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const float* pf,
+                     const float* xb, const float* vb, const float* pb, const float* coin,
+                     const float* u, int32_t strict, int64_t B, int32_t D, float* x_prop,
+                     float* v_prop, float* p, float* x_out, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Lattice integrator: gauge_dynamics.py:412-483 (_forward_lf/_backward_lf),
+ * :261-313 (transition_kernel), :195-259 (apply_transition).
+ * ------------------------------------------------------------------------ */
+typedef struct l2hmc_gauge_plan {
+  int32_t T, X;            /* lattice extents; D = 2*T*X */
+  int32_t num_steps;       /* N_LF */
+  int32_t hmc;             /* 1: S=T=Q=0 (gauge_dynamics.py:102-108), nets ignored */
+  float eps;
+  float reserved;
+  const float* masks;      /* [num_steps][D] 0/1, gauge_dynamics.py:651-661 */
+  l2hmc_dense_net xnet;    /* position_fn */
+  l2hmc_dense_net vnet;    /* momentum_fn */
+} l2hmc_gauge_plan;
+
+size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);
+
+/* One augmented leapfrog step IN PLACE on x, v: [rows][D]; dir: [rows] int32 per
+ * row (0 fwd, 1 bwd), or NULL = all forward.  `step` is the loop counter t of
+ * transition_kernel: backward rows use index num_steps-1-step for time and
+ * mask, as _backward_lf does internally.  logdet[rows] is ACCUMULATED (+=). */
+int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, int32_t step, float* x, float* v,
+                         const int32_t* dir, int64_t rows, float* logdet, void* ws, size_t ws_bytes,
+                         l2hmc_stream_t stream);
+
+/* Full trajectory of `rows` chain-direction pairs: x0, v0 -> x_out, v_out,
+ * sumlogdet, accept probability (any of the last two may be NULL). */
+int l2hmc_gauge_trajectory(const l2hmc_gauge_plan* plan, float beta, const float* x0, const float* v0,
+                           const int32_t* dir, int64_t rows, float* x_out, float* v_out,
+                           float* sumlogdet, float* p_accept, void* ws, size_t ws_bytes,
+                           l2hmc_stream_t stream);
+
+/* apply_transition on B chains.  v0_f, v0_b: [B][D] momenta for the two
+ * directions; coin, u: [B] uniforms.  both_directions=1 integrates forward AND
+ * backward for every chain like the reference and mixes (2B rows); 0 integrates
+ * only the direction each chain's coin selects (B rows; identical outputs when
+ * the unselected trajectory is finite). Outputs [B][D], [B][D], [B], [B][D]. */
+size_t l2hmc_gauge_transition_ws_bytes(const l2hmc_gauge_plan* plan, int64_t B, int32_t both_directions);
+int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, const float* x, const float* v0_f,
+                           const float* v0_b, const float* coin, const float* u, int64_t B,
+                           int32_t both_directions, float* x_prop, float* v_prop, float* p_accept,
+                           float* x_out, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Generic integrator on 2-D toy targets (MoG / SCG):
+ *   utils/dynamics.py:120-225,255-319; utils/sampler.py:28-59;
+ *   utils/distributions.py:32-39,63-68,151-158.
+ * Target: mixture of K Gaussians (K=1, log_const ignored => plain Gaussian).
+ *   energy(x) = -logsumexp_k( -0.5 (x-mu_k)^T P_k (x-mu_k) + log_const[k] ) / temperature
+ * ------------------------------------------------------------------------ */
+#define L2HMC_MAX_MIX 8
+#define L2HMC_MAX_SMALL_DIM 8
+typedef struct l2hmc_mog_target {
+  int32_t dim;                     /* <= L2HMC_MAX_SMALL_DIM */
+  int32_t K;                       /* <= L2HMC_MAX_MIX */
+  int32_t is_gaussian;             /* 1: energy = 0.5 (x-mu)^T P (x-mu) (distributions.py:63-68) */
+  float temperature;
+  const float* mu;                 /* [K][dim] */
+  const float* prec;               /* [K][dim][dim] inverse covariances */
+  const float* log_const;          /* [K] log(pi_k / sqrt((2pi)^dim det Sigma_k)) */
+} l2hmc_mog_target;
+
+typedef struct l2hmc_small_plan {
+  int32_t x_dim, num_nodes, trajectory_length, hmc;
+  float eps;
+  float reserved;
+  const float* masks;              /* [trajectory_length][x_dim] */
+  l2hmc_dense_net xnet, vnet;      /* q_tanh = 1, Ka = Kb = x_dim */
+  l2hmc_mog_target target;
+} l2hmc_small_plan;
+
+int l2hmc_mog_energy_grad(const l2hmc_mog_target* tgt, const float* x, int64_t rows, float* energy,
+                          float* grad, l2hmc_stream_t stream);
+
+/* Dynamics.forward / .backward (dir per row, NULL = all forward): whole
+ * trajectory per chain in one kernel. */
+int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const float* v0,
+                           const int32_t* dir, int64_t rows, float* x_out, float* v_out,
+                           float* sumlogdet, float* p_accept, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Counter-based RNG (Philox4x32-10) standing in for tf.random_normal /
+ * tf.random_uniform (gauge_dynamics.py:223,246,269).  Same (seed, offset, n)
+ * => same stream on any launch geometry.
+ * ------------------------------------------------------------------------ */
+int l2hmc_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream);
+int l2hmc_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2HMC_HIP_H */

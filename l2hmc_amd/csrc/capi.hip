@@ -1,0 +1,95 @@
+// Error plumbing of the C ABI + the counter-based RNG.
+#include "common.h"
+#include <string.h>
+
+namespace l2hmc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Block b of the stream is
+// philox(counter = {b_lo, b_hi, offset_lo, offset_hi}, key = {seed_lo, seed_hi});
+// element i of a fill is word (i & 3) of block (i >> 2).
+// ---------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0;
+    k1 += W1;
+  }
+}
+
+__device__ __forceinline__ float u01_open(uint32_t w) {   // (0, 1): 24 bits, centred
+  return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+template <bool NORMAL>
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                   uint64_t offset) {
+  const int64_t nblk = (n + 3) >> 2;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float v[4];
+    if (NORMAL) {
+      // Box-Muller on (c0, c1) and (c2, c3)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float u1 = u01_open(c[2 * h]), u2 = u01_open(c[2 * h + 1]);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        v[2 * h] = rad * cs;
+        v[2 * h + 1] = rad * sn;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+    }
+    const int64_t i0 = b << 2;
+    if (i0 + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+      *reinterpret_cast<float4*>(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int j = 0; j < 4 && i0 + j < n; ++j) out[i0 + j] = v[j];
+    }
+  }
+}
+
+template <bool NORMAL>
+static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  L2HMC_REQUIRE(n >= 0, "fill: n < 0");
+  if (n == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(out != nullptr, "fill: out is NULL");
+  const int64_t nblk = (n + 3) >> 2;
+  const int64_t grid = hmin(ceil_div(nblk, 256), 4096);
+  hipLaunchKernelGGL(fill_kernel<NORMAL>, dim3((unsigned)grid), dim3(256), 0, s, out, n, seed, offset);
+  L2HMC_CHECK_LAUNCH("fill");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
+extern "C" const char* l2hmc_last_error(void) { return g_err; }
+
+extern "C" int l2hmc_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream) {
+  return launch_fill<true>(out, n, seed, offset, (hipStream_t)stream);
+}
+extern "C" int l2hmc_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream) {
+  return launch_fill<false>(out, n, seed, offset, (hipStream_t)stream);
+}

@@ -1,0 +1,45 @@
+// Shared host/device helpers for libl2hmc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/l2hmc_hip.h"
+
+namespace l2hmc {
+
+void set_error(const char* fmt, ...);
+
+#define L2HMC_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::l2hmc::set_error(__VA_ARGS__);           \
+      return L2HMC_ERR_ARG;                      \
+    }                                            \
+  } while (0)
+
+#define L2HMC_CHECK_LAUNCH(what)                                              \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) {                                                   \
+      ::l2hmc::set_error("%s: %s", what, hipGetErrorString(e_));              \
+      return L2HMC_ERR_HIP;                                                   \
+    }                                                                         \
+  } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t hmin(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int hmax(int a, int b) { return a > b ? a : b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// sum across the 64 lanes of a wave; every lane gets the total (fixed tree => deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace l2hmc

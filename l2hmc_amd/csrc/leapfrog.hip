@@ -1,0 +1,576 @@
+// Leapfrog sub-updates (standalone forms), accept probability, direction
+// mixing / Metropolis-Hastings, and the host-side orchestration of the lattice
+// trajectory: l2hmc/dynamics/gauge_dynamics.py:195-313, :412-609.
+#include "stq_dense.h"
+#include <math.h>
+
+namespace l2hmc {
+
+// =====================================================================
+// standalone sub-updates: one wave per row, S/T/Q may be NULL (= 0, the
+// hmc=True nets of gauge_dynamics.py:102-108).  dir: per-row array or NULL
+// with `dir_all` for every row.
+// =====================================================================
+__global__ __launch_bounds__(256) void lf_update_v_kernel(
+    const float* v, const float* __restrict__ grad, const float* __restrict__ S,
+    const float* __restrict__ T, const float* __restrict__ Q, float eps, const int* __restrict__ dir,
+    int dir_all, int64_t rows, int D, float* v_out, float* __restrict__ logdet,
+    int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d = dir ? dir[row] : dir_all;
+  float ld = 0.f;
+  for (int c = lane; c < D; c += kWave) {
+    const int64_t i = row * D + c;
+    const float Sv = S ? S[i] : 0.f, Tv = T ? T[i] : 0.f, Qv = Q ? Q[i] : 0.f;
+    const float s = (d ? -0.5f : 0.5f) * eps * Sv;
+    const float kick = 0.5f * eps * (expf(eps * Qv) * grad[i] - Tv);
+    const float vv = v[i];
+    v_out[i] = d ? expf(s) * (vv + kick) : vv * expf(s) - kick;
+    ld += s;
+  }
+  ld = wave_sum(ld);
+  if (lane == 0 && logdet) logdet[row] = accumulate ? logdet[row] + ld : ld;
+}
+
+__global__ __launch_bounds__(256) void lf_update_x_kernel(
+    const float* x, const float* __restrict__ v, const float* __restrict__ keep_f,
+    const float* __restrict__ keep_b, const float* __restrict__ S, const float* __restrict__ T,
+    const float* __restrict__ Q, float eps, const int* __restrict__ dir, int dir_all, int64_t rows,
+    int D, float* x_out, float* __restrict__ logdet, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d = dir ? dir[row] : dir_all;
+  const float* keep = d ? keep_b : keep_f;
+  float ld = 0.f;
+  for (int c = lane; c < D; c += kWave) {
+    const int64_t i = row * D + c;
+    const float Sv = S ? S[i] : 0.f, Tv = T ? T[i] : 0.f, Qv = Q ? Q[i] : 0.f;
+    const float k = keep[c];
+    const float s = (d ? -eps : eps) * Sv;
+    const float drift = eps * (expf(eps * Qv) * v[i] + Tv);
+    const float xx = x[i];
+    const float upd = d ? expf(s) * (xx - drift) : xx * expf(s) + drift;
+    x_out[i] = k * xx + (1.f - k) * upd;
+    ld += (1.f - k) * s;
+  }
+  ld = wave_sum(ld);
+  if (lane == 0 && logdet) logdet[row] = accumulate ? logdet[row] + ld : ld;
+}
+
+// keep_inv[c] = 1 - keep[c]   (the m-bar of gauge_dynamics.py:671-673), for all steps at once
+__global__ void invert_mask_kernel(const float* __restrict__ m, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.f - m[i];
+}
+
+// logdet[row] (+)= sum_cb part[row][cb]
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int ncb, int64_t rows,
+                                    float* __restrict__ out, int accumulate) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = 0; c < ncb; ++c) s += part[r * ncb + c];
+  out[r] = accumulate ? out[r] + s : s;
+}
+
+// gauge_dynamics.py:592-609 from Hamiltonians
+__global__ void accept_prob_kernel(const float* __restrict__ h_old, const float* __restrict__ h_new,
+                                   const float* __restrict__ sld, int64_t n, float* __restrict__ p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = fminf(h_old[i] - h_new[i] + sld[i], 0.f);
+  const float pr = expf(e);
+  p[i] = isfinite(pr) ? pr : 0.f;
+}
+
+// Same from the pieces the trajectory has at hand.  The difference of the two
+// O(100) Hamiltonians is formed in fp64 from the fp32 action / kinetic sums so
+// that p carries no cancellation error beyond the inputs' own rounding.
+__global__ void accept_from_parts_kernel(const float* __restrict__ act0, const float* __restrict__ kin0,
+                                         const float* __restrict__ act1, const float* __restrict__ kin1,
+                                         const float* __restrict__ ld_part, int ncb, float beta,
+                                         int64_t n, float* __restrict__ sumlogdet,
+                                         float* __restrict__ p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < ncb; ++c) s += ld_part[i * ncb + c];
+  if (sumlogdet) sumlogdet[i] = s;
+  if (p) {
+    const double dh = (double)beta * ((double)act0[i] - (double)act1[i]) +
+                      ((double)kin0[i] - (double)kin1[i]) + (double)s;
+    const float pr = expf((float)fmin(dh, 0.0));
+    p[i] = isfinite(pr) ? pr : 0.f;
+  }
+}
+
+// gauge_dynamics.py:221-257 / utils/sampler.py:33-59
+__global__ __launch_bounds__(256) void mix_accept_kernel(
+    const float* __restrict__ x, const float* __restrict__ xf, const float* __restrict__ vf,
+    const float* __restrict__ pf, const float* __restrict__ xb, const float* __restrict__ vb,
+    const float* __restrict__ pb, const float* __restrict__ coin, const float* __restrict__ u,
+    int strict, int64_t B, int D, float* __restrict__ x_prop, float* __restrict__ v_prop,
+    float* __restrict__ p_out, float* __restrict__ x_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const bool fwd = strict ? (coin[row] > 0.5f) : (coin[row] != 0.f);
+  const float fm = fwd ? 1.f : 0.f, bm = 1.f - fm;
+  // keep the reference's arithmetic (mask * a + (1 - mask) * b) so non-finite
+  // values in the unselected branch propagate exactly as they do there
+  const float p = fm * pf[row] + bm * pb[row];
+  const bool acc = u ? (strict ? (p > u[row]) : (p - u[row] >= 0.f)) : false;
+  const float am = acc ? 1.f : 0.f;
+  if (lane == 0 && p_out) p_out[row] = p;
+  for (int c = lane; c < D; c += kWave) {
+    const int64_t i = row * D + c;
+    const float xp = fm * xf[i] + bm * xb[i];
+    if (x_prop) x_prop[i] = xp;
+    if (v_prop) v_prop[i] = fm * vf[i] + bm * vb[i];
+    if (x_out) x_out[i] = strict ? (am * xp + (1.f - am) * x[i]) : (acc ? xp : x[i]);
+  }
+}
+
+// selected-direction mode: dir = coin > 0.5 ? fwd : bwd; v0 = that direction's momentum
+__global__ __launch_bounds__(256) void select_dir_kernel(const float* __restrict__ coin,
+                                                         const float* __restrict__ v0_f,
+                                                         const float* __restrict__ v0_b, int64_t B, int D,
+                                                         int* __restrict__ dir, float* __restrict__ v) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const int d = (coin[row] > 0.5f) ? 0 : 1;
+  if (lane == 0) dir[row] = d;
+  const float* src = d ? v0_b : v0_f;
+  for (int c = lane; c < D; c += kWave) v[row * D + c] = src[row * D + c];
+}
+
+__global__ void fill_dir_kernel(int* __restrict__ dir, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * B) dir[i] = (i < B) ? 0 : 1;
+}
+
+// selected-direction MH step (x_prop already is the selected trajectory)
+__global__ __launch_bounds__(256) void accept_selected_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ xs,
+                                                              const float* __restrict__ p,
+                                                              const float* __restrict__ u, int64_t B, int D,
+                                                              float* __restrict__ x_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float am = (p[row] > u[row]) ? 1.f : 0.f;
+  for (int c = lane; c < D; c += kWave) {
+    const int64_t i = row * D + c;
+    x_out[i] = am * xs[i] + (1.f - am) * x[i];
+  }
+}
+
+// =====================================================================
+// host orchestration
+// =====================================================================
+struct GaugeWs {
+  float* h1; float* h2; float* g; float* ld_part; float* mask_inv;
+  float* act0; float* kin0; float* act1; float* kin1;
+  size_t bytes;
+};
+
+static int gauge_hmax(const l2hmc_gauge_plan* p) { return p->hmc ? 0 : hmax(p->xnet.H, p->vnet.H); }
+static int gauge_ncb(const l2hmc_gauge_plan* p) { return (int)ceil_div(2 * p->T * p->X, 32); }
+
+static GaugeWs carve_gauge_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws) {
+  const int D = 2 * p->T * p->X;
+  const int H = gauge_hmax(p);
+  char* base = static_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* ptr = reinterpret_cast<float*>(base + off);
+    off += align_up(nfloat * sizeof(float), 256);
+    return ptr;
+  };
+  GaugeWs w;
+  w.h1 = take((size_t)rows * H);
+  w.h2 = take((size_t)rows * H);
+  w.g = take((size_t)rows * D);
+  w.ld_part = take((size_t)rows * gauge_ncb(p));
+  w.mask_inv = take((size_t)p->num_steps * D);
+  w.act0 = take(rows);
+  w.kin0 = take(rows);
+  w.act1 = take(rows);
+  w.kin1 = take(rows);
+  w.bytes = off;
+  return w;
+}
+
+static int check_plan(const l2hmc_gauge_plan* p) {
+  L2HMC_REQUIRE(p != nullptr, "plan is NULL");
+  L2HMC_REQUIRE(p->T > 0 && p->X > 0 && p->num_steps > 0, "plan: bad T/X/num_steps");
+  L2HMC_REQUIRE(p->masks != nullptr, "plan: masks is NULL");
+  const int D = 2 * p->T * p->X;
+  if (!p->hmc) {
+    const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
+    for (const l2hmc_dense_net* n : nets) {
+      L2HMC_REQUIRE(n->D == D, "plan: net D=%d != lattice x_dim=%d", n->D, D);
+      L2HMC_REQUIRE(dense_net_supported(n),
+                    "plan: net widths (Ka=%d, Kb=%d, H=%d) must be positive multiples of 32", n->Ka, n->Kb,
+                    n->H);
+      L2HMC_REQUIRE(n->Ka == D && n->Kb == D, "plan: generic net expects Ka=Kb=x_dim (got %d, %d)", n->Ka,
+                    n->Kb);
+      L2HMC_REQUIRE(n->w1_t && n->wt && n->b1 && n->wh_t && n->bh && n->whd_t && n->bhd && n->coeff_s &&
+                        n->coeff_q,
+                    "plan: net has NULL weight pointer");
+    }
+    L2HMC_REQUIRE(D % 4 == 0, "plan: x_dim must be a multiple of 4");
+  }
+  return L2HMC_OK;
+}
+
+// one S/T/Q evaluation of `net` on (a, b*mask), fused with the v or x update
+static int net_update(const l2hmc_dense_net* net, const float* a, const float* b, const float* cm_f,
+                      const float* cm_b, const int* dir, const float tcs[4], int64_t rows, int mode,
+                      float* x, float* v, const float* g, const float* keep_f, const float* keep_b,
+                      float eps, const GaugeWs& w, int ncb, hipStream_t stream) {
+  GemmReluArgs l1{};
+  l1.A1 = a; l1.lda1 = net->Ka; l1.K1 = net->Ka;
+  l1.A2 = b; l1.lda2 = net->Kb;
+  l1.cmask_f = cm_f; l1.cmask_b = cm_b;
+  l1.dir = dir;
+  l1.Wt = net->w1_t; l1.K = net->Ka + net->Kb; l1.N = net->H;
+  l1.bias = net->b1; l1.wt0 = net->wt; l1.wt1 = net->wt + net->H;
+  l1.tc_f = tcs[0]; l1.ts_f = tcs[1]; l1.tc_b = tcs[2]; l1.ts_b = tcs[3];
+  l1.out = w.h1; l1.ldo = net->H; l1.rows = rows;
+  if (int e = launch_gemm_relu(l1, stream)) return e;
+
+  GemmReluArgs l2{};
+  l2.A1 = w.h1; l2.lda1 = net->H; l2.K1 = net->H;
+  l2.Wt = net->wh_t; l2.K = net->H; l2.N = net->H;
+  l2.bias = net->bh;
+  l2.out = w.h2; l2.ldo = net->H; l2.rows = rows;
+  if (int e = launch_gemm_relu(l2, stream)) return e;
+
+  HeadsArgs h{};
+  h.A = w.h2; h.lda = net->H; h.K = net->H;
+  h.Wt = net->whd_t; h.bhd = net->bhd; h.cs = net->coeff_s; h.cq = net->coeff_q;
+  h.q_tanh = net->q_tanh; h.D = net->D; h.rows = rows; h.mode = mode;
+  h.x = x; h.v = v; h.g = g; h.dir = dir; h.keep_f = keep_f; h.keep_b = keep_b; h.eps = eps;
+  h.ld_part = w.ld_part; h.ncb = ncb;
+  return launch_heads(h, stream);
+}
+
+// one augmented leapfrog step in place; log-det goes to w.ld_part (+=)
+static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float* x, float* v,
+                         const int* dir, int64_t rows, const GaugeWs& w, hipStream_t stream) {
+  const int D = 2 * p->T * p->X;
+  const int N = p->num_steps;
+  const int sf = step, sb = N - 1 - step;   // gauge_dynamics.py:453-457
+  // _format_time (:625-633): fp32 cos/sin of 2*pi*i/N
+  float tcs[4];
+  {
+    const float two_pi = (float)(2.0 * M_PI);
+    const float af = two_pi * (float)sf / (float)N, ab = two_pi * (float)sb / (float)N;
+    tcs[0] = cosf(af); tcs[1] = sinf(af); tcs[2] = cosf(ab); tcs[3] = sinf(ab);
+  }
+  const float* m_f = p->masks + (size_t)sf * D;
+  const float* m_b = p->masks + (size_t)sb * D;
+  const float* mi_f = w.mask_inv + (size_t)sf * D;
+  const float* mi_b = w.mask_inv + (size_t)sb * D;
+  const int ncb = gauge_ncb(p);
+  const unsigned rgrid = (unsigned)ceil_div(rows, 4);
+
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      // position sub-updates between the two momentum half-kicks.
+      // forward (:428-438): (m, m_inv) then (m_inv, m); backward (:466-476): (m_inv, m) then (m, m_inv)
+      for (int sub = 0; sub < 2; ++sub) {
+        const float* kf = sub == 0 ? m_f : mi_f;
+        const float* kb = sub == 0 ? mi_b : m_b;
+        if (p->hmc) {
+          hipLaunchKernelGGL(lf_update_x_kernel, dim3(rgrid), dim3(256), 0, stream, x, v, kf, kb, nullptr,
+                             nullptr, nullptr, p->eps, dir, 0, rows, D, x, nullptr, 0);
+          L2HMC_CHECK_LAUNCH("lf_update_x");
+        } else {
+          if (int e = net_update(&p->xnet, v, x, kf, kb, dir, tcs, rows, /*mode x*/ 2, x, v, nullptr, kf, kb,
+                                 p->eps, w, ncb, stream))
+            return e;
+        }
+      }
+    }
+    // momentum half-kick (:423-425 and :440-442)
+    if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, nullptr, w.g, nullptr, nullptr, stream))
+      return e;
+    if (p->hmc) {
+      hipLaunchKernelGGL(lf_update_v_kernel, dim3(rgrid), dim3(256), 0, stream, v, w.g, nullptr, nullptr,
+                         nullptr, p->eps, dir, 0, rows, D, v, nullptr, 0);
+      L2HMC_CHECK_LAUNCH("lf_update_v");
+    } else {
+      if (int e = net_update(&p->vnet, x, w.g, nullptr, nullptr, dir, tcs, rows, /*mode v*/ 1, x, v, w.g,
+                             nullptr, nullptr, p->eps, w, ncb, stream))
+        return e;
+    }
+  }
+  return L2HMC_OK;
+}
+
+static int prepare_ws(const l2hmc_gauge_plan* p, int64_t rows, const GaugeWs& w, hipStream_t stream) {
+  const int D = 2 * p->T * p->X;
+  const int n = p->num_steps * D;
+  hipLaunchKernelGGL(invert_mask_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, p->masks,
+                     w.mask_inv, n);
+  L2HMC_CHECK_LAUNCH("invert_mask");
+  if (hipMemsetAsync(w.ld_part, 0, sizeof(float) * (size_t)rows * gauge_ncb(p), stream) != hipSuccess) {
+    set_error("hipMemsetAsync(ld_part) failed");
+    return L2HMC_ERR_HIP;
+  }
+  return L2HMC_OK;
+}
+
+// x, v: [rows][D] integrated in place over all num_steps; optional sumlogdet / p
+static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, float* v, const int* dir,
+                              int64_t rows, float* sumlogdet, float* p_accept, const GaugeWs& w,
+                              hipStream_t stream) {
+  const int D = 2 * p->T * p->X;
+  if (int e = prepare_ws(p, rows, w, stream)) return e;
+  if (p_accept) {
+    if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, w.act0, nullptr, nullptr, nullptr, stream))
+      return e;
+    if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin0, stream)) return e;
+  }
+  for (int step = 0; step < p->num_steps; ++step)
+    if (int e = leapfrog_step(p, beta, step, x, v, dir, rows, w, stream)) return e;
+  if (p_accept) {
+    if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, w.act1, nullptr, nullptr, nullptr, stream))
+      return e;
+    if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin1, stream)) return e;
+  }
+  if (p_accept || sumlogdet) {
+    hipLaunchKernelGGL(accept_from_parts_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, stream,
+                       w.act0, w.kin0, w.act1, w.kin1, w.ld_part, gauge_ncb(p), beta, rows, sumlogdet,
+                       p_accept);
+    L2HMC_CHECK_LAUNCH("accept_from_parts");
+  }
+  return L2HMC_OK;
+}
+
+static int copy_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    set_error("hipMemcpyAsync failed");
+    return L2HMC_ERR_HIP;
+  }
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+// ---------------------------------------------------------------------------
+extern "C" int l2hmc_lf_update_v(const float* v, const float* grad, const float* S, const float* T,
+                                 const float* Q, float eps, int32_t dir, int64_t rows, int32_t D,
+                                 float* v_out, float* logdet, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(rows >= 0 && D > 0 && (dir == 0 || dir == 1), "lf_update_v: bad arguments");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(v && grad && v_out, "lf_update_v: NULL pointer");
+  hipLaunchKernelGGL(lf_update_v_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     v, grad, S, T, Q, eps, nullptr, dir, rows, D, v_out, logdet, 0);
+  L2HMC_CHECK_LAUNCH("lf_update_v");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_lf_update_x(const float* x, const float* v, const float* keep, const float* S,
+                                 const float* T, const float* Q, float eps, int32_t dir, int64_t rows,
+                                 int32_t D, float* x_out, float* logdet, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(rows >= 0 && D > 0 && (dir == 0 || dir == 1), "lf_update_x: bad arguments");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && v && keep && x_out, "lf_update_x: NULL pointer");
+  hipLaunchKernelGGL(lf_update_x_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, v, keep, keep, S, T, Q, eps, nullptr, dir, rows, D, x_out, logdet, 0);
+  L2HMC_CHECK_LAUNCH("lf_update_x");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_accept_prob(const float* h_old, const float* h_new, const float* sumlogdet, int64_t n,
+                                 float* p, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(n >= 0, "accept_prob: n < 0");
+  if (n == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(h_old && h_new && sumlogdet && p, "accept_prob: NULL pointer");
+  hipLaunchKernelGGL(accept_prob_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     h_old, h_new, sumlogdet, n, p);
+  L2HMC_CHECK_LAUNCH("accept_prob");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const float* pf,
+                                const float* xb, const float* vb, const float* pb, const float* coin,
+                                const float* u, int32_t strict, int64_t B, int32_t D, float* x_prop,
+                                float* v_prop, float* p, float* x_out, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(B >= 0 && D > 0, "mix_accept: bad shape");
+  if (B == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(xf && vf && pf && xb && vb && pb && coin, "mix_accept: NULL pointer");
+  L2HMC_REQUIRE(x_out == nullptr || (x && u), "mix_accept: x_out needs x and u");
+  hipLaunchKernelGGL(mix_accept_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     xf, vf, pf, xb, vb, pb, coin, u, strict, B, D, x_prop, v_prop, p, x_out);
+  L2HMC_CHECK_LAUNCH("mix_accept");
+  return L2HMC_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" size_t l2hmc_stq_ws_bytes(int64_t rows, int32_t H) {
+  return 2 * align_up((size_t)rows * H * sizeof(float), 256);
+}
+
+extern "C" int l2hmc_stq_dense(const l2hmc_dense_net* net, const float* a, const float* b, const float* bmask,
+                               float t_cos, float t_sin, int64_t rows, float* S, float* T, float* Q, void* ws,
+                               size_t ws_bytes, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(net != nullptr && rows >= 0, "stq_dense: bad arguments");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(dense_net_supported(net), "stq_dense: widths (Ka=%d, Kb=%d, H=%d) must be multiples of 32",
+                net->Ka, net->Kb, net->H);
+  L2HMC_REQUIRE(a && b && S && T && Q && ws, "stq_dense: NULL pointer");
+  if (ws_bytes < l2hmc_stq_ws_bytes(rows, net->H)) {
+    set_error("stq_dense: workspace %zu < %zu bytes", ws_bytes, l2hmc_stq_ws_bytes(rows, net->H));
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* h1 = static_cast<float*>(ws);
+  float* h2 = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)rows * net->H * sizeof(float), 256));
+  GemmReluArgs l1{};
+  l1.A1 = a; l1.lda1 = net->Ka; l1.K1 = net->Ka;
+  l1.A2 = b; l1.lda2 = net->Kb;
+  l1.cmask_f = bmask; l1.cmask_b = bmask;
+  l1.Wt = net->w1_t; l1.K = net->Ka + net->Kb; l1.N = net->H;
+  l1.bias = net->b1; l1.wt0 = net->wt; l1.wt1 = net->wt + net->H;
+  l1.tc_f = l1.tc_b = t_cos; l1.ts_f = l1.ts_b = t_sin;
+  l1.out = h1; l1.ldo = net->H; l1.rows = rows;
+  if (int e = launch_gemm_relu(l1, s)) return e;
+  GemmReluArgs l2{};
+  l2.A1 = h1; l2.lda1 = net->H; l2.K1 = net->H;
+  l2.Wt = net->wh_t; l2.K = net->H; l2.N = net->H;
+  l2.bias = net->bh; l2.out = h2; l2.ldo = net->H; l2.rows = rows;
+  if (int e = launch_gemm_relu(l2, s)) return e;
+  HeadsArgs h{};
+  h.A = h2; h.lda = net->H; h.K = net->H;
+  h.Wt = net->whd_t; h.bhd = net->bhd; h.cs = net->coeff_s; h.cq = net->coeff_q;
+  h.q_tanh = net->q_tanh; h.D = net->D; h.rows = rows; h.mode = 0;
+  h.S = S; h.T = T; h.Q = Q;
+  return launch_heads(h, s);
+}
+
+// ---------------------------------------------------------------------------
+extern "C" size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows) {
+  if (!plan || rows < 0) return 0;
+  return carve_gauge_ws(plan, rows, nullptr).bytes;
+}
+
+extern "C" int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, int32_t step, float* x, float* v,
+                                    const int32_t* dir, int64_t rows, float* logdet, void* ws, size_t ws_bytes,
+                                    l2hmc_stream_t stream) {
+  if (int e = check_plan(plan)) return e;
+  L2HMC_REQUIRE(rows >= 0 && step >= 0 && step < plan->num_steps, "gauge_leapfrog: bad rows/step");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && v && ws, "gauge_leapfrog: NULL pointer");
+  const GaugeWs w = carve_gauge_ws(plan, rows, ws);
+  if (ws_bytes < w.bytes) {
+    set_error("gauge_leapfrog: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = prepare_ws(plan, rows, w, s)) return e;
+  if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s)) return e;
+  if (logdet) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, w.ld_part,
+                       gauge_ncb(plan), rows, logdet, 1);
+    L2HMC_CHECK_LAUNCH("reduce_parts");
+  }
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_gauge_trajectory(const l2hmc_gauge_plan* plan, float beta, const float* x0,
+                                      const float* v0, const int32_t* dir, int64_t rows, float* x_out,
+                                      float* v_out, float* sumlogdet, float* p_accept, void* ws,
+                                      size_t ws_bytes, l2hmc_stream_t stream) {
+  if (int e = check_plan(plan)) return e;
+  L2HMC_REQUIRE(rows >= 0, "gauge_trajectory: rows < 0");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x0 && v0 && x_out && v_out && ws, "gauge_trajectory: NULL pointer");
+  const GaugeWs w = carve_gauge_ws(plan, rows, ws);
+  if (ws_bytes < w.bytes) {
+    set_error("gauge_trajectory: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nb = sizeof(float) * (size_t)rows * 2 * plan->T * plan->X;
+  if (x_out != x0)
+    if (int e = copy_async(x_out, x0, nb, s)) return e;
+  if (v_out != v0)
+    if (int e = copy_async(v_out, v0, nb, s)) return e;
+  return trajectory_inplace(plan, beta, x_out, v_out, dir, rows, sumlogdet, p_accept, w, s);
+}
+
+// transition workspace = [X | V | p | dir] for R rows, then the trajectory workspace
+static size_t transition_head_bytes(int64_t R, int D) {
+  return 2 * align_up(sizeof(float) * (size_t)R * D, 256) + align_up(sizeof(float) * (size_t)R, 256) +
+         align_up(sizeof(int) * (size_t)R, 256);
+}
+
+extern "C" size_t l2hmc_gauge_transition_ws_bytes(const l2hmc_gauge_plan* plan, int64_t B,
+                                                  int32_t both_directions) {
+  if (!plan || B < 0) return 0;
+  const int64_t R = both_directions ? 2 * B : B;
+  return transition_head_bytes(R, 2 * plan->T * plan->X) + carve_gauge_ws(plan, R, nullptr).bytes;
+}
+
+extern "C" int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, const float* x,
+                                      const float* v0_f, const float* v0_b, const float* coin, const float* u,
+                                      int64_t B, int32_t both_directions, float* x_prop, float* v_prop,
+                                      float* p_accept, float* x_out, void* ws, size_t ws_bytes,
+                                      l2hmc_stream_t stream) {
+  if (int e = check_plan(plan)) return e;
+  L2HMC_REQUIRE(B >= 0, "gauge_transition: B < 0");
+  if (B == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && v0_f && v0_b && coin && u && x_prop && v_prop && p_accept && x_out && ws,
+                "gauge_transition: NULL pointer");
+  const int D = 2 * plan->T * plan->X;
+  const int64_t R = both_directions ? 2 * B : B;
+  const size_t need = l2hmc_gauge_transition_ws_bytes(plan, B, both_directions);
+  if (ws_bytes < need) {
+    set_error("gauge_transition: workspace %zu < %zu bytes", ws_bytes, need);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  char* base = static_cast<char*>(ws);
+  const size_t xv = align_up(sizeof(float) * (size_t)R * D, 256);
+  float* Xw = reinterpret_cast<float*>(base);
+  float* Vw = reinterpret_cast<float*>(base + xv);
+  float* Pw = reinterpret_cast<float*>(base + 2 * xv);
+  int* dirw = reinterpret_cast<int*>(base + 2 * xv + align_up(sizeof(float) * (size_t)R, 256));
+  const GaugeWs w = carve_gauge_ws(plan, R, base + transition_head_bytes(R, D));
+  const size_t nb = sizeof(float) * (size_t)B * D;
+
+  if (both_directions) {
+    // rows [0, B): forward with v0_f; rows [B, 2B): backward with v0_b (gauge_dynamics.py:211-218)
+    if (int e = copy_async(Xw, x, nb, s)) return e;
+    if (int e = copy_async(Xw + (size_t)B * D, x, nb, s)) return e;
+    if (int e = copy_async(Vw, v0_f, nb, s)) return e;
+    if (int e = copy_async(Vw + (size_t)B * D, v0_b, nb, s)) return e;
+    hipLaunchKernelGGL(fill_dir_kernel, dim3((unsigned)ceil_div(2 * B, 256)), dim3(256), 0, s, dirw, B);
+    L2HMC_CHECK_LAUNCH("fill_dir");
+    if (int e = trajectory_inplace(plan, beta, Xw, Vw, dirw, R, nullptr, Pw, w, s)) return e;
+    hipLaunchKernelGGL(mix_accept_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, x, Xw, Vw, Pw,
+                       Xw + (size_t)B * D, Vw + (size_t)B * D, Pw + B, coin, u, 1, B, D, x_prop, v_prop,
+                       p_accept, x_out);
+    L2HMC_CHECK_LAUNCH("mix_accept");
+  } else {
+    if (int e = copy_async(x_prop, x, nb, s)) return e;
+    hipLaunchKernelGGL(select_dir_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, coin, v0_f, v0_b, B,
+                       D, dirw, v_prop);
+    L2HMC_CHECK_LAUNCH("select_dir");
+    if (int e = trajectory_inplace(plan, beta, x_prop, v_prop, dirw, R, nullptr, p_accept, w, s)) return e;
+    hipLaunchKernelGGL(accept_selected_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, x, x_prop,
+                       p_accept, u, B, D, x_out);
+    L2HMC_CHECK_LAUNCH("accept_selected");
+  }
+  return L2HMC_OK;
+}

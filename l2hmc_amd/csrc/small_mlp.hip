@@ -1,0 +1,375 @@
+// Generic L2HMC integrator on low-dimensional toy targets (MoG / strongly
+// correlated Gaussian), one thread per chain, whole trajectory in one launch.
+//
+// Replaces the tf.while_loop graph of
+//   l2hmc/utils/dynamics.py:120-225 (_forward_step/_backward_step), :255-319
+//   l2hmc/utils/network.py:89-114   (`network` MLP, ScaleTanh on S and F)
+//   l2hmc/utils/distributions.py:32-39,63-68,151-158 (energies; gradient by
+//   autodiff there, closed form here)
+// These configurations (x_dim 2, 10-50 hidden units) are launch/latency bound:
+// an MFMA tile would be >90 % padding, so the MLP runs on the VALU with both
+// networks' weights resident in LDS (broadcast reads) and the chain state in
+// registers; x and v are read once and written once per trajectory.
+#include "common.h"
+
+namespace l2hmc {
+
+constexpr int kSmallThreads = 64;
+constexpr int kMaxDim = L2HMC_MAX_SMALL_DIM;
+constexpr int kMaxMix = L2HMC_MAX_MIX;
+
+struct SmallNetView {   // offsets (floats) into the per-net LDS image
+  int w1, wt, b1, wh, bh, whd, bhd, es, eq, size;
+};
+
+__host__ __device__ inline SmallNetView small_net_view(int HP, int dim) {
+  SmallNetView v;
+  int o = 0;
+  v.w1 = o; o += HP * 2 * dim;
+  v.wt = o; o += 2 * HP;
+  v.b1 = o; o += HP;
+  v.wh = o; o += HP * HP;
+  v.bh = o; o += HP;
+  v.whd = o; o += 3 * dim * HP;
+  v.bhd = o; o += 3 * dim;
+  v.es = o; o += dim;
+  v.eq = o; o += dim;
+  v.size = (o + 3) & ~3;
+  return v;
+}
+
+template <int HP>
+__device__ void load_net(const l2hmc_dense_net& n, float* L, int dim) {
+  const SmallNetView v = small_net_view(HP, dim);
+  const int H = n.H, tid = threadIdx.x;
+  for (int i = tid; i < v.size; i += kSmallThreads) L[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < H * 2 * dim; i += kSmallThreads) L[v.w1 + i] = n.w1_t[i];
+  for (int i = tid; i < 2 * H; i += kSmallThreads) L[v.wt + (i / H) * HP + (i % H)] = n.wt[i];
+  for (int i = tid; i < H; i += kSmallThreads) {
+    L[v.b1 + i] = n.b1[i];
+    L[v.bh + i] = n.bh[i];
+  }
+  for (int i = tid; i < H * H; i += kSmallThreads) L[v.wh + (i / H) * HP + (i % H)] = n.wh_t[i];
+  for (int i = tid; i < 3 * dim * H; i += kSmallThreads) L[v.whd + (i / H) * HP + (i % H)] = n.whd_t[i];
+  for (int i = tid; i < 3 * dim; i += kSmallThreads) L[v.bhd + i] = n.bhd[i];
+  for (int i = tid; i < dim; i += kSmallThreads) {
+    L[v.es + i] = expf(n.coeff_s[i]);
+    L[v.eq + i] = expf(n.coeff_q[i]);
+  }
+}
+
+// (S, T, Q) = net([a, b, t]); h2 goes through a per-thread LDS column.
+template <int HP>
+__device__ void net_eval(const float* L, int dim, int H, int q_tanh, const float a[kMaxDim],
+                         const float b[kMaxDim], float tc, float ts, float* h2col, float S[kMaxDim],
+                         float T[kMaxDim], float Q[kMaxDim]) {
+  const SmallNetView v = small_net_view(HP, dim);
+  float h1[HP];
+#pragma unroll
+  for (int n = 0; n < HP; ++n) {
+    float acc = L[v.b1 + n] + tc * L[v.wt + n] + ts * L[v.wt + HP + n];
+#pragma unroll
+    for (int k = 0; k < kMaxDim; ++k)
+      if (k < dim) acc += a[k] * L[v.w1 + n * 2 * dim + k] + b[k] * L[v.w1 + n * 2 * dim + dim + k];
+    h1[n] = fmaxf(acc, 0.f);
+  }
+  for (int n = 0; n < H; ++n) {
+    float acc = L[v.bh + n];
+    const float* w = L + v.wh + n * HP;
+#pragma unroll
+    for (int k = 0; k < HP; ++k) acc += h1[k] * w[k];
+    h2col[n * kSmallThreads] = fmaxf(acc, 0.f);
+  }
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) {
+    if (d < dim) {
+      float s = L[v.bhd + d], t = L[v.bhd + dim + d], q = L[v.bhd + 2 * dim + d];
+      const float* ws = L + v.whd + (0 * dim + d) * HP;
+      const float* wt = L + v.whd + (1 * dim + d) * HP;
+      const float* wq = L + v.whd + (2 * dim + d) * HP;
+      for (int k = 0; k < H; ++k) {
+        const float h = h2col[k * kSmallThreads];
+        s += h * ws[k];
+        t += h * wt[k];
+        q += h * wq[k];
+      }
+      S[d] = tanhf(s) * L[v.es + d];
+      T[d] = t;
+      Q[d] = (q_tanh ? tanhf(q) : q) * L[v.eq + d];
+    }
+  }
+}
+
+struct TargetView {   // LDS image of l2hmc_mog_target
+  int mu, prec, logc, size;
+};
+__host__ __device__ inline TargetView target_view(int dim, int K) {
+  TargetView t;
+  t.mu = 0;
+  t.prec = K * dim;
+  t.logc = t.prec + K * dim * dim;
+  t.size = (t.logc + K + 3) & ~3;
+  return t;
+}
+
+// distributions.py:151-158 (GMM), :63-68 (Gaussian); gradient in closed form.
+__device__ void energy_grad(const float* Lt, int dim, int K, int is_gaussian, float inv_temp,
+                            const float x[kMaxDim], float* E, float g[kMaxDim]) {
+  const TargetView tv = target_view(dim, K);
+  float V[kMaxMix];
+  float vmax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kMaxMix; ++k) {
+    if (k < K) {
+      float quad = 0.f;
+      for (int i = 0; i < dim; ++i) {
+        float pd = 0.f;
+        for (int j = 0; j < dim; ++j) pd += Lt[tv.prec + (k * dim + i) * dim + j] * (x[j] - Lt[tv.mu + k * dim + j]);
+        quad += (x[i] - Lt[tv.mu + k * dim + i]) * pd;
+      }
+      V[k] = -0.5f * quad + (is_gaussian ? 0.f : Lt[tv.logc + k]);
+      vmax = fmaxf(vmax, V[k]);
+    }
+  }
+  float sw = 0.f;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) g[d] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxMix; ++k) {
+    if (k < K) {
+      const float w = is_gaussian ? 1.f : expf(V[k] - vmax);
+      sw += w;
+#pragma unroll
+      for (int i = 0; i < kMaxDim; ++i) {
+        if (i < dim) {
+          float gi = 0.f;
+          for (int j = 0; j < dim; ++j) {
+            const float dj = x[j] - Lt[tv.mu + k * dim + j];
+            gi += (Lt[tv.prec + (k * dim + i) * dim + j] + Lt[tv.prec + (k * dim + j) * dim + i]) * dj;
+          }
+          g[i] += w * 0.5f * gi;
+        }
+      }
+    }
+  }
+  const float e = is_gaussian ? -V[0] : -(vmax + logf(sw));
+  *E = e * inv_temp;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) g[d] = g[d] / sw * inv_temp;
+}
+
+__device__ void load_target(const l2hmc_mog_target& t, float* Lt) {
+  const TargetView tv = target_view(t.dim, t.K);
+  for (int i = threadIdx.x; i < t.K * t.dim; i += kSmallThreads) Lt[tv.mu + i] = t.mu[i];
+  for (int i = threadIdx.x; i < t.K * t.dim * t.dim; i += kSmallThreads) Lt[tv.prec + i] = t.prec[i];
+  for (int i = threadIdx.x; i < t.K; i += kSmallThreads) Lt[tv.logc + i] = t.is_gaussian ? 0.f : t.log_const[i];
+}
+
+__global__ __launch_bounds__(kSmallThreads) void mog_energy_grad_kernel(l2hmc_mog_target t,
+                                                                        const float* __restrict__ x,
+                                                                        int64_t rows,
+                                                                        float* __restrict__ energy,
+                                                                        float* __restrict__ grad) {
+  extern __shared__ float lds[];
+  load_target(t, lds);
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
+  if (r >= rows) return;
+  float xv[kMaxDim], g[kMaxDim], E;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) xv[d] = d < t.dim ? x[r * t.dim + d] : 0.f;
+  energy_grad(lds, t.dim, t.K, t.is_gaussian, 1.f / t.temperature, xv, &E, g);
+  if (energy) energy[r] = E;
+  if (grad) {
+#pragma unroll
+    for (int d = 0; d < kMaxDim; ++d)
+      if (d < t.dim) grad[r * t.dim + d] = g[d];
+  }
+}
+
+struct SmallTrajArgs {
+  l2hmc_small_plan plan;
+  const float* x0; const float* v0; const int* dir; int64_t rows;
+  float* x_out; float* v_out; float* sumlogdet; float* p_accept;
+};
+
+template <int HP>
+__global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs a) {
+  extern __shared__ float lds[];
+  const l2hmc_small_plan& P = a.plan;
+  const int dim = P.x_dim, H = P.num_nodes, N = P.trajectory_length;
+  const SmallNetView nv = small_net_view(HP, dim);
+  const TargetView tv = target_view(P.target.dim, P.target.K);
+  float* Lx = lds;
+  float* Lv = Lx + nv.size;
+  float* Lt = Lv + nv.size;
+  float* Lm = Lt + tv.size;                       // masks [N][dim]
+  float* h2 = Lm + ((N * dim + 3) & ~3);          // [HP][64] per-thread columns
+  if (!P.hmc) {
+    load_net<HP>(P.xnet, Lx, dim);
+    load_net<HP>(P.vnet, Lv, dim);
+  }
+  load_target(P.target, Lt);
+  for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
+  __syncthreads();
+
+  const int64_t r = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
+  if (r >= a.rows) return;
+  float* h2col = h2 + threadIdx.x;
+  const int bwd = a.dir ? a.dir[r] : 0;
+  const float eps = P.eps;
+  const float inv_temp = 1.f / P.target.temperature;
+  const int isg = P.target.is_gaussian, K = P.target.K;
+
+  float x[kMaxDim], v[kMaxDim];
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) {
+    x[d] = d < dim ? a.x0[r * dim + d] : 0.f;
+    v[d] = d < dim ? a.v0[r * dim + d] : 0.f;
+  }
+  float g[kMaxDim], E0, E1;
+  energy_grad(Lt, dim, K, isg, inv_temp, x, &E0, g);
+  float kin0 = 0.f;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) kin0 += v[d] * v[d];
+  const float H0 = E0 + 0.5f * kin0;
+
+  float logdet = 0.f;
+  float S[kMaxDim], T[kMaxDim], Q[kMaxDim], bin[kMaxDim];
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) S[d] = T[d] = Q[d] = 0.f;
+  for (int it = 0; it < N; ++it) {
+    const int step = bwd ? N - 1 - it : it;       // utils/dynamics.py:294-296
+    const float arg = 6.28318530717958647692f * (float)step / (float)N;
+    const float tc = cosf(arg), ts = sinf(arg);
+    const float* m = Lm + step * dim;
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+        // two position sub-updates; keep mask m then 1-m (fwd) / 1-m then m (bwd)
+        for (int sub = 0; sub < 2; ++sub) {
+          const bool keep_is_m = (sub == 0) != (bwd != 0);
+#pragma unroll
+          for (int d = 0; d < kMaxDim; ++d) {
+            const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
+            bin[d] = k * x[d];
+          }
+          if (!P.hmc) net_eval<HP>(Lx, dim, H, P.xnet.q_tanh, v, bin, tc, ts, h2col, S, T, Q);
+#pragma unroll
+          for (int d = 0; d < kMaxDim; ++d) {
+            if (d < dim) {
+              const float k = keep_is_m ? m[d] : 1.f - m[d];
+              const float s = (bwd ? -eps : eps) * S[d];
+              const float drift = eps * (expf(eps * Q[d]) * v[d] + T[d]);
+              const float upd = bwd ? expf(s) * (x[d] - drift) : x[d] * expf(s) + drift;
+              x[d] = k * x[d] + (1.f - k) * upd;
+              logdet += (1.f - k) * s;
+            }
+          }
+        }
+        energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+      }
+      if (!P.hmc) net_eval<HP>(Lv, dim, H, P.vnet.q_tanh, x, g, tc, ts, h2col, S, T, Q);
+#pragma unroll
+      for (int d = 0; d < kMaxDim; ++d) {
+        if (d < dim) {
+          const float s = (bwd ? -0.5f : 0.5f) * eps * S[d];
+          const float kick = 0.5f * eps * (expf(eps * Q[d]) * g[d] - T[d]);
+          v[d] = bwd ? expf(s) * (v[d] + kick) : v[d] * expf(s) - kick;
+          logdet += s;
+        }
+      }
+    }
+  }
+  energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+  float kin1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) kin1 += v[d] * v[d];
+  const float H1 = E1 + 0.5f * kin1;
+#pragma unroll
+  for (int d = 0; d < kMaxDim; ++d) {
+    if (d < dim) {
+      a.x_out[r * dim + d] = x[d];
+      a.v_out[r * dim + d] = v[d];
+    }
+  }
+  if (a.sumlogdet) a.sumlogdet[r] = logdet;
+  if (a.p_accept) {
+    const float pr = expf(fminf(H0 - H1 + logdet, 0.f));   // utils/dynamics.py:312-319
+    a.p_accept[r] = isfinite(pr) ? pr : 0.f;
+  }
+}
+
+static int check_target(const l2hmc_mog_target* t) {
+  L2HMC_REQUIRE(t != nullptr, "target is NULL");
+  L2HMC_REQUIRE(t->dim > 0 && t->dim <= kMaxDim && t->K > 0 && t->K <= kMaxMix,
+                "target: dim=%d (max %d), K=%d (max %d)", t->dim, kMaxDim, t->K, kMaxMix);
+  L2HMC_REQUIRE(t->mu && t->prec && (t->is_gaussian || t->log_const), "target: NULL parameter pointer");
+  L2HMC_REQUIRE(!t->is_gaussian || t->K == 1, "target: gaussian needs K == 1");
+  L2HMC_REQUIRE(t->temperature > 0.f, "target: temperature must be > 0");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" int l2hmc_mog_energy_grad(const l2hmc_mog_target* tgt, const float* x, int64_t rows, float* energy,
+                                     float* grad, l2hmc_stream_t stream) {
+  if (int e = check_target(tgt)) return e;
+  L2HMC_REQUIRE(rows >= 0, "mog_energy_grad: rows < 0");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x != nullptr, "mog_energy_grad: x is NULL");
+  const size_t lds = sizeof(float) * target_view(tgt->dim, tgt->K).size;
+  hipLaunchKernelGGL(mog_energy_grad_kernel, dim3((unsigned)ceil_div(rows, kSmallThreads)), dim3(kSmallThreads),
+                     lds, (hipStream_t)stream, *tgt, x, rows, energy, grad);
+  L2HMC_CHECK_LAUNCH("mog_energy_grad");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const float* v0,
+                                      const int32_t* dir, int64_t rows, float* x_out, float* v_out,
+                                      float* sumlogdet, float* p_accept, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(plan != nullptr, "small_trajectory: plan is NULL");
+  if (int e = check_target(&plan->target)) return e;
+  const int dim = plan->x_dim, H = plan->num_nodes, N = plan->trajectory_length;
+  L2HMC_REQUIRE(dim == plan->target.dim, "small_trajectory: x_dim=%d != target dim=%d", dim, plan->target.dim);
+  L2HMC_REQUIRE(N > 0 && plan->masks != nullptr, "small_trajectory: bad trajectory_length / masks");
+  L2HMC_REQUIRE(rows >= 0, "small_trajectory: rows < 0");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x0 && v0 && x_out && v_out, "small_trajectory: NULL pointer");
+  int HP = 16;
+  if (!plan->hmc) {
+    L2HMC_REQUIRE(H > 0 && H <= 64, "small_trajectory: num_nodes=%d unsupported (1..64)", H);
+    const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
+    for (const l2hmc_dense_net* n : nets) {
+      L2HMC_REQUIRE(n->D == dim && n->Ka == dim && n->Kb == dim && n->H == H,
+                    "small_trajectory: net shape (D=%d Ka=%d Kb=%d H=%d) != (x_dim=%d, num_nodes=%d)", n->D,
+                    n->Ka, n->Kb, n->H, dim, H);
+      L2HMC_REQUIRE(n->w1_t && n->wt && n->b1 && n->wh_t && n->bh && n->whd_t && n->bhd && n->coeff_s &&
+                        n->coeff_q,
+                    "small_trajectory: net has NULL weight pointer");
+    }
+    HP = H <= 16 ? 16 : 64;
+  }
+  SmallTrajArgs a{*plan, x0, v0, dir, rows, x_out, v_out, sumlogdet, p_accept};
+  const size_t lds = sizeof(float) * (2 * (size_t)small_net_view(HP, dim).size +
+                                      target_view(dim, plan->target.K).size + ((N * dim + 3) & ~3) +
+                                      (size_t)HP * kSmallThreads);
+  L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
+  const dim3 grid((unsigned)ceil_div(rows, kSmallThreads));
+  static bool attr_set = false;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (HP == 16)
+    hipLaunchKernelGGL(small_traj_kernel<16>, grid, dim3(kSmallThreads), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(small_traj_kernel<64>, grid, dim3(kSmallThreads), lds, (hipStream_t)stream, a);
+  L2HMC_CHECK_LAUNCH("small_trajectory");
+  return L2HMC_OK;
+}

@@ -1,0 +1,49 @@
+// Launch descriptors shared by stq_dense.hip (kernels) and leapfrog.hip (orchestration).
+#pragma once
+#include "common.h"
+
+namespace l2hmc {
+
+// L1 / L2:  out = relu(A . Wt^T + bias [+ t-term])
+struct GemmReluArgs {
+  const float* A1; int lda1; int K1;   // columns [0, K1) of A
+  const float* A2; int lda2;           // columns [K1, K) of A (NULL if K1 == K)
+  const float* cmask_f;                // optional [K-K1] multiplier on A2, forward rows
+  const float* cmask_b;                //                                   backward rows
+  const int* dir;                      // [rows] 0/1 or NULL (all forward)
+  const float* Wt; int K; int N;       // [N][K]
+  const float* bias;                   // [N]
+  const float* wt0; const float* wt1;  // t_layer kernel rows [N] each, or NULL
+  float tc_f, ts_f, tc_b, ts_b;        // (cos, sin) of the step's time, per direction
+  float* out; int ldo;
+  int64_t rows;
+  int mtiles, ntiles;
+};
+
+// heads: (S,T,Q) = h2 . Whd^T + bhd, then materialise or fused v/x update
+enum HeadsMode { kHeadsMaterialise = 0, kHeadsUpdateV = 1, kHeadsUpdateX = 2 };
+
+struct HeadsArgs {
+  const float* A; int lda; int K;        // h2 [rows][K]
+  const float* Wt;                       // [3][D][K]
+  const float* bhd;                      // [3][D]
+  const float* cs; const float* cq;      // [D]
+  int q_tanh; int D; int64_t rows;
+  int mode;
+  float* S; float* T; float* Q;          // mode 0 outputs [rows][D]
+  float* x; float* v;                    // updated in place (v: mode 1, x: mode 2)
+  const float* g;                        // force (mode 1)
+  const int* dir;                        // [rows] or NULL
+  const float* keep_f; const float* keep_b;  // [D] keep masks per direction (mode 2)
+  float eps;
+  float* ld_part; int ncb;               // [rows][ncb] log-det partials, += own slot
+  int mtiles, ntiles;
+};
+
+int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
+int launch_heads(HeadsArgs& a, hipStream_t stream);
+int dense_net_supported(const l2hmc_dense_net* n);
+int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
+                           float* force, float* avg_plaq, float* top_charge, hipStream_t stream);
+
+}  // namespace l2hmc

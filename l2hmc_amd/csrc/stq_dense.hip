@@ -1,0 +1,423 @@
+// Dense scale/translate/transform network on fp32 MFMA (gfx950), with the
+// leapfrog sub-update fused into the heads' epilogue.
+//
+// Replaces, per network call, the 6 matmuls + ~10 element-wise TF kernels of
+//   l2hmc/network/generic_net.py:129-146 (and the dense trunk of
+//   network/conv_net.py:264-280, utils/network.py:89-114)
+// and, in the fused modes, the ~12 element-wise ops + reduce_sum of
+//   l2hmc/dynamics/gauge_dynamics.py:486-508, :511-534, :537-561, :565-590.
+//
+// Three launches per network call, every operand k-contiguous ("NT" GEMM):
+//   L1    h1 = relu([a | b*mask] . W1^T + b1 + t.Wt)     K = Ka + Kb
+//   L2    h2 = relu(h1 . Wh^T + bh)                       K = H
+//   heads (S,T,Q) = h2 . Whd^T + bhd  -> tanh/exp(coeff) -> v or x update
+//         + per-row log-det partial sums (wave shuffles, fixed order).
+// S, T, Q never touch HBM in the fused modes; h1/h2 are [rows][H] scratch that
+// stays L2/MALL-resident at the benchmark sizes.
+//
+// Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 are
+// bitwise a k-ordered fmaf chain (no TF32/xf32 on gfx950), which is what the
+// 1e-5 parity bar needs.  Tiles are sized for 64-wide waves: 4 waves per
+// workgroup, one per SIMD; LDS rows are padded so the 16-byte fragment reads
+// are bank-conflict free (stride 36 floats for the 32-row fragments, 40 for the
+// 16-row ones).  Tile ids are remapped so tiles sharing activation rows land on
+// one XCD (shared L2).
+#include "stq_dense.h"
+
+namespace l2hmc {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;            // k-tile
+constexpr int kGemmThreads = 256;  // 4 waves
+
+// ---- XCD-aware tile id: blocks b, b+8, ... share an XCD, give each XCD a
+// contiguous run of logical tiles (bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+// =====================================================================
+// L1 / L2:  out = relu(A . Wt^T + bias [+ t-term])
+// =====================================================================
+
+
+template <int BM>
+__global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
+  constexpr int BN = 128;
+  constexpr int LDK = BK + 4;              // 36 floats = 144 B rows: conflict-free b128 reads
+  constexpr int MT = BM / 64;              // 32x32 tiles per wave along M (wave grid 2 x 2)
+  constexpr int NT = 2;                    // wave covers 64 columns
+  constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
+  constexpr int B_CH = BN * (BK / 4) / kGemmThreads;
+  constexpr int STAGE = (BM + BN) * LDK;   // one A|B buffer pair
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
+  const int64_t m0 = (int64_t)mt_id * BM;
+  const int n0 = nt_id * BN;
+
+  // --- staging coordinates (fixed per thread)
+  int a_row[A_CH], a_kc[A_CH];
+  bool a_ok[A_CH];
+  int a_dir[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    a_row[i] = c >> 3;
+    a_kc[i] = (c & 7) * 4;
+    a_ok[i] = (m0 + a_row[i]) < p.rows;
+    a_dir[i] = (p.dir && a_ok[i]) ? p.dir[m0 + a_row[i]] : 0;
+  }
+  int b_row[B_CH], b_kc[B_CH];
+  bool b_ok[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    b_row[i] = c >> 3;
+    b_kc[i] = (c & 7) * 4;
+    b_ok[i] = (n0 + b_row[i]) < p.N;
+  }
+
+  f32x4 ra[A_CH], rb[B_CH];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok[i]) {
+        if (k0 < p.K1) {
+          v = *reinterpret_cast<const f32x4*>(p.A1 + (m0 + a_row[i]) * p.lda1 + k0 + a_kc[i]);
+        } else {
+          const int kk = k0 - p.K1 + a_kc[i];
+          v = *reinterpret_cast<const f32x4*>(p.A2 + (m0 + a_row[i]) * p.lda2 + kk);
+          if (p.cmask_f) {
+            const float* cm = a_dir[i] ? p.cmask_b : p.cmask_f;
+            v *= *reinterpret_cast<const f32x4*>(cm + kk);
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + b_row[i]) * p.K + k0 + b_kc[i]);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* ab = lds + buf * STAGE;
+    float* bb = ab + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      *reinterpret_cast<f32x4*>(ab + a_row[i] * LDK + a_kc[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      *reinterpret_cast<f32x4*>(bb + b_row[i] * LDK + b_kc[i]) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
+    const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + half * 4;
+    const float* bs = lds + cur * STAGE + BM * LDK + (wn * 64 + r) * LDK + half * 4;
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + kq * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + kq * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: + bias (+ t.Wt), relu, store.  C layout of 32x32 MFMA:
+  // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + r;
+    const bool cok = col < p.N;
+    const float bj = cok ? p.bias[col] : 0.f;
+    const float w0 = (cok && p.wt0) ? p.wt0[col] : 0.f;
+    const float w1 = (cok && p.wt0) ? p.wt1[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < p.rows && cok) {
+          const int d = p.dir ? p.dir[row] : 0;
+          const float tc = d ? p.tc_b : p.tc_f;
+          const float ts = d ? p.ts_b : p.ts_f;
+          float h = acc[i][j][e] + bj;
+          h += tc * w0 + ts * w1;
+          p.out[row * p.ldo + col] = fmaxf(h, 0.f);
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================
+// heads: (S,T,Q) = h2 . Whd^T + bhd, then materialise or fused v/x update.
+// Workgroup tile: 64 rows x 32 output columns x 3 heads, so S, T and Q of one
+// (row, col) sit in the same lane.  16x16x4 MFMAs: wave w owns rows 16w..16w+15.
+// =====================================================================
+
+
+__global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
+  constexpr int BM = 64, BNH = 32, NB = 3 * BNH;
+  constexpr int LDK = BK + 8;             // 40 floats: conflict-free for the 16-row fragment reads
+  constexpr int A_CH = BM * (BK / 4) / kGemmThreads;   // 2
+  constexpr int B_CH = NB * (BK / 4) / kGemmThreads;   // 3
+  constexpr int STAGE = (BM + NB) * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
+  const int64_t m0 = (int64_t)mt_id * BM;
+  const int n0 = nt_id * BNH;
+
+  int a_row[A_CH], a_kc[A_CH];
+  bool a_ok[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    a_row[i] = c >> 3;
+    a_kc[i] = (c & 7) * 4;
+    a_ok[i] = (m0 + a_row[i]) < p.rows;
+  }
+  int b_row[B_CH], b_kc[B_CH];
+  int64_t b_src[B_CH];
+  bool b_ok[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    b_row[i] = c >> 3;                      // 0..95 = head * 32 + nn
+    b_kc[i] = (c & 7) * 4;
+    const int hd = b_row[i] >> 5, nn = b_row[i] & 31;
+    b_ok[i] = (n0 + nn) < p.D;
+    b_src[i] = ((int64_t)hd * p.D + n0 + nn) * p.K;
+  }
+
+  f32x4 ra[A_CH], rb[B_CH];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(p.A + (m0 + a_row[i]) * p.lda + k0 + a_kc[i]);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(p.Wt + b_src[i] + k0 + b_kc[i]);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* ab = lds + buf * STAGE;
+    float* bb = ab + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      *reinterpret_cast<f32x4*>(ab + a_row[i] * LDK + a_kc[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      *reinterpret_cast<f32x4*>(bb + b_row[i] * LDK + b_kc[i]) = rb[i];
+  };
+
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* as = lds + cur * STAGE + (wave * 16 + r) * LDK + q * 4;
+    const float* bs = lds + cur * STAGE + BM * LDK + r * LDK + q * 4;
+#pragma unroll
+    for (int kh = 0; kh < BK / 16; ++kh) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(as + kh * 16);
+      f32x4 bf[3][2];
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bf[h][j] = *reinterpret_cast<const f32x4*>(bs + (h * 32 + j * 16) * LDK + kh * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[h][j][e], acc[h][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue.  C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  float ld[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + j * 16 + r;
+    const bool cok = col < p.D;
+    const float b_s = cok ? p.bhd[col] : 0.f;
+    const float b_t = cok ? p.bhd[p.D + col] : 0.f;
+    const float b_q = cok ? p.bhd[2 * p.D + col] : 0.f;
+    const float e_s = cok ? expf(p.cs[col]) : 0.f;
+    const float e_q = cok ? expf(p.cq[col]) : 0.f;
+    float kf = 0.f, kb = 0.f;
+    if (p.mode == kHeadsUpdateX && cok) {
+      kf = p.keep_f[col];
+      kb = p.keep_b[col];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wave * 16 + q * 4 + e;
+      if (row >= p.rows || !cok) continue;
+      const float S = tanhf(acc[0][j][e] + b_s) * e_s;
+      const float T = acc[1][j][e] + b_t;
+      float Q = acc[2][j][e] + b_q;
+      Q = (p.q_tanh ? tanhf(Q) : Q) * e_q;
+      const int64_t idx = row * p.D + col;
+      if (p.mode == kHeadsMaterialise) {
+        p.S[idx] = S;
+        p.T[idx] = T;
+        p.Q[idx] = Q;
+      } else {
+        const int d = p.dir ? p.dir[row] : 0;
+        const float eps = p.eps;
+        if (p.mode == kHeadsUpdateV) {
+          // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
+          const float g = p.g[idx], v = p.v[idx];
+          const float s = (d ? -0.5f : 0.5f) * eps * S;
+          const float tq = eps * Q;
+          const float kick = 0.5f * eps * (expf(tq) * g - T);
+          p.v[idx] = d ? expf(s) * (v + kick) : v * expf(s) - kick;
+          ld[e] += s;
+        } else {
+          // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd)
+          const float keep = d ? kb : kf;
+          const float x = p.x[idx], v = p.v[idx];
+          const float s = (d ? -eps : eps) * S;
+          const float tq = eps * Q;
+          const float drift = eps * (expf(tq) * v + T);
+          const float upd = d ? expf(s) * (x - drift) : x * expf(s) + drift;
+          p.x[idx] = keep * x + (1.f - keep) * upd;
+          ld[e] += (1.f - keep) * s;
+        }
+      }
+    }
+  }
+  if (p.mode != kHeadsMaterialise && p.ld_part) {
+    // reduce over the 16 lanes (columns) of each quarter; rows q*4+e stay apart
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = ld[e];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 1, 64);
+      const int64_t row = m0 + wave * 16 + q * 4 + e;
+      if (r == 0 && row < p.rows) p.ld_part[row * p.ncb + nt_id] += t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// host-side launchers (used by the C ABI in capi.hip)
+// ---------------------------------------------------------------------
+static int check_ptr16(const void* p, const char* what) {
+  L2HMC_REQUIRE(p != nullptr, "%s is NULL", what);
+  L2HMC_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "%s is not 16-byte aligned", what);
+  return L2HMC_OK;
+}
+
+int dense_net_supported(const l2hmc_dense_net* n) {
+  return n->Ka > 0 && n->Kb > 0 && n->H > 0 && n->D > 0 && (n->Ka % BK) == 0 && (n->Kb % BK) == 0 &&
+         (n->H % BK) == 0;
+}
+
+int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
+  L2HMC_REQUIRE(a.K % BK == 0 && a.K1 % BK == 0 && a.K1 <= a.K, "gemm: K=%d K1=%d must be multiples of %d",
+                a.K, a.K1, BK);
+  L2HMC_REQUIRE(a.lda1 % 4 == 0 && (a.A2 == nullptr || a.lda2 % 4 == 0) && a.ldo > 0, "gemm: bad strides");
+  if (int e = check_ptr16(a.A1, "gemm A1")) return e;
+  if (a.K1 < a.K)
+    if (int e = check_ptr16(a.A2, "gemm A2")) return e;
+  if (int e = check_ptr16(a.Wt, "gemm W")) return e;
+  if (a.cmask_f) {
+    if (int e = check_ptr16(a.cmask_f, "gemm mask")) return e;
+    if (int e = check_ptr16(a.cmask_b, "gemm mask (bwd)")) return e;
+  }
+  a.ntiles = (int)ceil_div(a.N, 128);
+  // 128-row tiles once they still fill the chip (>= 2 tiles per CU), else 64-row tiles
+  const int64_t t128 = ceil_div(a.rows, 128) * a.ntiles;
+  if (t128 >= 512) {
+    a.mtiles = (int)ceil_div(a.rows, 128);
+    hipLaunchKernelGGL(gemm_relu_kernel<128>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  } else {
+    a.mtiles = (int)ceil_div(a.rows, 64);
+    hipLaunchKernelGGL(gemm_relu_kernel<64>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  }
+  L2HMC_CHECK_LAUNCH("gemm_relu");
+  return L2HMC_OK;
+}
+
+int launch_heads(HeadsArgs& a, hipStream_t stream) {
+  L2HMC_REQUIRE(a.K % BK == 0 && a.lda % 4 == 0, "heads: K=%d must be a multiple of %d", a.K, BK);
+  if (int e = check_ptr16(a.A, "heads A")) return e;
+  if (int e = check_ptr16(a.Wt, "heads W")) return e;
+  a.mtiles = (int)ceil_div(a.rows, 64);
+  a.ntiles = (int)ceil_div(a.D, 32);
+  L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
+  hipLaunchKernelGGL(heads_kernel, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  L2HMC_CHECK_LAUNCH("heads");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc

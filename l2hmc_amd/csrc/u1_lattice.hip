@@ -1,0 +1,214 @@
+// 2D U(1) lattice kernels for gfx950: plaquette sums, action, force, observables.
+//
+// Replaces the ~9 stock TF ops (4 strided slices, 2 rolls, cos, reduce, and the
+// autodiff graph twice that size) of
+//   l2hmc/lattice/lattice.py:337-362, :285-313
+//   l2hmc/gauge_model.py:659-725
+//   l2hmc/dynamics/gauge_dynamics.py:698-709 (force = autodiff of beta*S)
+// with one pass: a chain's links are read once (coalesced), its plaquette
+// neighbourhood is staged in LDS with the periodic wrap resolved there, sin P is
+// shared through LDS for the two links that need each plaquette, and the
+// per-chain sums use a fixed shuffle tree (bit-reproducible).
+//
+// HBM-bound: 8*D + 4..12 bytes per chain (read x, write force + scalars).
+#include "common.h"
+
+namespace l2hmc {
+
+constexpr int kLatThreads = 256;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kPi = 3.14159265358979323846f;
+
+// One workgroup handles `cpw` consecutive chains (cpw*sites <= 256 threads busy)
+// or, for sites >= 256, one chain with several sites per thread.
+__global__ __launch_bounds__(kLatThreads) void u1_action_force_kernel(
+    const float* __restrict__ x, int64_t rows, int T, int X, float beta, int cpw,
+    float* __restrict__ action, float* __restrict__ force, float* __restrict__ avg_plaq,
+    float* __restrict__ top_charge) {
+  extern __shared__ float lds[];
+  const int sites = T * X;
+  const int D = 2 * sites;
+  float* xs = lds;                 // [cpw][sites][2]
+  float* sp = lds + cpw * D;       // [cpw][sites]   sin P
+  float* red = sp + cpw * sites;   // [256][3] or [4][3] partials
+
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * cpw;
+  const int nrow = (int)min((int64_t)cpw, rows - row0);
+  const int nflt = nrow * D;
+  const float* src = x + row0 * D;
+
+  // coalesced copy of nrow*D contiguous floats
+  if ((D & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(xs);
+    for (int i = tid; i < nflt / 4; i += kLatThreads) d4[i] = s4[i];
+  } else {
+    for (int i = tid; i < nflt; i += kLatThreads) xs[i] = src[i];
+  }
+  __syncthreads();
+
+  const int work = nrow * sites;
+  float a_act = 0.f, a_plq = 0.f, a_chg = 0.f;
+  for (int s = tid; s < work; s += kLatThreads) {
+    const int c = s / sites;
+    const int site = s - c * sites;
+    const int i = site / X, j = site - i * X;
+    const float* xc = xs + c * D;
+    const int jp = (j + 1 == X) ? 0 : j + 1;
+    const int ip = (i + 1 == T) ? 0 : i + 1;
+    // gauge_model.py:676-679: x0[i,j] - x1[i,j] - x0[i,j+1] + x1[i+1,j]
+    const float P = xc[2 * site] - xc[2 * site + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
+    float sn, cs;
+    sincosf(P, &sn, &cs);
+    sp[s] = sn;
+    a_act += 1.f - cs;
+    a_plq += cs;
+    a_chg += P - kTwoPi * floorf((P + kPi) / kTwoPi);   // project_angle, gauge_model.py:78-80
+  }
+
+  // per-chain reduction, deterministic
+  const bool wave_aligned = (sites % kWave) == 0;
+  if (wave_aligned) {
+    a_act = wave_sum(a_act);
+    a_plq = wave_sum(a_plq);
+    a_chg = wave_sum(a_chg);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) {
+      red[w * 3 + 0] = a_act;
+      red[w * 3 + 1] = a_plq;
+      red[w * 3 + 2] = a_chg;
+    }
+  } else {
+    red[tid * 3 + 0] = a_act;
+    red[tid * 3 + 1] = a_plq;
+    red[tid * 3 + 2] = a_chg;
+  }
+  __syncthreads();
+  if (tid < nrow) {
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    int lo, hi;
+    if (wave_aligned) {
+      const int wpc = (sites >= kLatThreads) ? (kLatThreads / kWave) : (sites / kWave);
+      lo = tid * wpc;
+      hi = lo + wpc;
+    } else if (sites >= kLatThreads) {
+      lo = 0;
+      hi = kLatThreads;
+    } else {
+      lo = tid * sites;
+      hi = lo + sites;
+    }
+    for (int k = lo; k < hi; ++k) {
+      r0 += red[k * 3 + 0];
+      r1 += red[k * 3 + 1];
+      r2 += red[k * 3 + 2];
+    }
+    const int64_t r = row0 + tid;
+    if (action) action[r] = r0;
+    if (avg_plaq) avg_plaq[r] = r1 / (float)sites;
+    if (top_charge) top_charge[r] = r2 / kTwoPi;
+  }
+
+  if (force) {
+    float2* dst = reinterpret_cast<float2*>(force + row0 * D);
+    for (int s = tid; s < work; s += kLatThreads) {
+      const int c = s / sites;
+      const int site = s - c * sites;
+      const int i = site / X, j = site - i * X;
+      const float* spc = sp + c * sites;
+      const int jm = (j == 0) ? X - 1 : j - 1;
+      const int im = (i == 0) ? T - 1 : i - 1;
+      const float sP = spc[site];
+      float2 g;
+      g.x = beta * (sP - spc[i * X + jm]);       // d/dx0[i,j]
+      g.y = beta * (-sP + spc[im * X + j]);      // d/dx1[i,j]
+      dst[s] = g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void u1_plaq_sums_kernel(const float* __restrict__ x, int64_t rows,
+                                                           int T, int X, float* __restrict__ plaq) {
+  const int sites = T * X;
+  const int64_t total = rows * sites;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = g / sites;
+    const int site = (int)(g - r * sites);
+    const int i = site / X, j = site - i * X;
+    const int jp = (j + 1 == X) ? 0 : j + 1;
+    const int ip = (i + 1 == T) ? 0 : i + 1;
+    const float* xc = x + r * 2 * sites;
+    plaq[g] = xc[2 * site] - xc[2 * site + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
+  }
+}
+
+// one wave per row: 0.5 * sum v^2
+__global__ __launch_bounds__(256) void kinetic_kernel(const float* __restrict__ v, int64_t rows, int D,
+                                                      float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* vr = v + r * D;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += kWave) {
+    const float t = vr[d];
+    acc += t * t;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[r] = 0.5f * acc;
+}
+
+int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
+                           float* force, float* avg_plaq, float* top_charge, hipStream_t stream) {
+  const int sites = T * X;
+  const int cpw = sites >= kLatThreads ? 1 : kLatThreads / sites;
+  const size_t lds = sizeof(float) * ((size_t)cpw * 3 * sites + 3 * kLatThreads);
+  L2HMC_REQUIRE(lds <= 160 * 1024, "u1_action_force: lattice %dx%d does not fit LDS", T, X);
+  const int64_t grid = ceil_div(rows, cpw);
+  hipLaunchKernelGGL(u1_action_force_kernel, dim3((unsigned)grid), dim3(kLatThreads), lds, stream, x,
+                     rows, T, X, beta, cpw, action, force, avg_plaq, top_charge);
+  L2HMC_CHECK_LAUNCH("u1_action_force");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" int l2hmc_u1_action_force(const float* x, int64_t rows, int32_t T, int32_t X, float beta,
+                                     float* action, float* force, float* avg_plaq, float* top_charge,
+                                     l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(rows >= 0 && T > 0 && X > 0, "u1_action_force: bad shape rows=%lld T=%d X=%d",
+                (long long)rows, T, X);
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x != nullptr, "u1_action_force: x is NULL");
+  L2HMC_REQUIRE(ceil_div(rows, 1) < (1ll << 31), "u1_action_force: too many rows");
+  return launch_u1_action_force(x, rows, T, X, beta, action, force, avg_plaq, top_charge,
+                                (hipStream_t)stream);
+}
+
+extern "C" int l2hmc_u1_plaq_sums(const float* x, int64_t rows, int32_t T, int32_t X, float* plaq,
+                                  l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(rows >= 0 && T > 0 && X > 0, "u1_plaq_sums: bad shape");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && plaq, "u1_plaq_sums: NULL pointer");
+  const int64_t total = rows * T * X;
+  const int64_t grid = hmin(ceil_div(total, 256), 2048);
+  hipLaunchKernelGGL(u1_plaq_sums_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows,
+                     T, X, plaq);
+  L2HMC_CHECK_LAUNCH("u1_plaq_sums");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_kinetic_energy(const float* v, int64_t rows, int32_t D, float* out,
+                                    l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(rows >= 0 && D > 0, "kinetic_energy: bad shape");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(v && out, "kinetic_energy: NULL pointer");
+  hipLaunchKernelGGL(kinetic_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     v, rows, D, out);
+  L2HMC_CHECK_LAUNCH("kinetic_energy");
+  return L2HMC_OK;
+}

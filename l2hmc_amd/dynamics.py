@@ -1,0 +1,140 @@
+"""`Dynamics` with the reference's surface (l2hmc/utils/dynamics.py:34-319) for
+the toy targets (MoG / Gaussian), backed by l2hmc_small_trajectory: the whole
+trajectory of every chain runs in one HIP launch."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Dynamics(object):
+    def __init__(self, x_dim, energy_function, trajectory_length=10, eps=0.1, hmc=False, net_factory=None,
+                 eps_trainable=True, use_temperature=False, device=None, seed=42):
+        self.x_dim = x_dim
+        self.use_temperature = use_temperature
+        self.temperature = 1.0             # the reference feeds a placeholder (:48)
+        self._device = device or torch.device("cuda", torch.cuda.current_device())
+        # quirk Q2: eps = exp(alpha), alpha = log(eps) (:51-60)
+        self.alpha = torch.log(torch.tensor(float(eps), dtype=torch.float32))
+        self.eps_trainable = eps_trainable
+        self._fn = energy_function
+        self._target = getattr(energy_function, "target", None)
+        if self._target is None:
+            raise TypeError("Dynamics on the HIP path needs an energy function made by "
+                            "l2hmc_amd.distributions (GMM / Gaussian).get_energy_function(); arbitrary "
+                            "Python callables cannot run inside the fused trajectory kernel")
+        if self._target.dim != x_dim:
+            raise ValueError(f"x_dim={x_dim} but the target has dimension {self._target.dim}")
+        self.trajectory_length = int(trajectory_length)
+        self.hmc = hmc
+        self._init_mask()
+        if hmc:                             # :75-78
+            self.XNet = lambda inp: [torch.zeros_like(inp[0]) for _ in range(3)]
+            self.VNet = lambda inp: [torch.zeros_like(inp[0]) for _ in range(3)]
+        else:
+            self.XNet = net_factory(x_dim, scope='XNet', factor=2.0)
+            self.VNet = net_factory(x_dim, scope='VNet', factor=1.0)
+        self._seed, self._draws = int(seed), 0
+
+    @property
+    def eps(self):
+        return torch.exp(self.alpha)
+
+    def _init_mask(self):
+        """:85-96 (legacy global NumPy stream)."""
+        mask_per_step = []
+        for _ in range(self.trajectory_length):
+            ind = np.random.permutation(np.arange(self.x_dim))[:int(self.x_dim / 2)]
+            m = np.zeros((self.x_dim,))
+            m[ind] = 1
+            mask_per_step.append(m)
+        self.set_masks(np.stack(mask_per_step))
+
+    def set_masks(self, masks):
+        masks = np.asarray(masks, dtype=np.float32)
+        if masks.shape != (self.trajectory_length, self.x_dim):
+            raise ValueError(f"masks: expected {(self.trajectory_length, self.x_dim)}, got {masks.shape}")
+        self.mask = _lib.as_dev(masks, self._device)
+
+    def _get_mask(self, step):
+        m = self.mask[int(step)]
+        return m, 1. - m
+
+    def _format_time(self, t, tile=1):
+        """:105-110."""
+        arg = np.float32(2 * np.pi) * np.float32(t) / np.float32(self.trajectory_length)
+        return torch.tensor([[np.cos(arg), np.sin(arg)]], dtype=torch.float32).repeat(tile, 1)
+
+    def _temp(self):
+        return float(self.temperature) if self.use_temperature else 1.0
+
+    def kinetic(self, v):
+        v = _lib.as_dev(v, self._device)
+        out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+        _lib.check(_lib.lib().l2hmc_kinetic_energy(v.data_ptr(), v.shape[0], v.shape[1], out.data_ptr(),
+                                                   _lib.stream_ptr()))
+        return out
+
+    def energy(self, x, aux=None):
+        """:227-236."""
+        return self._target.energy_grad(x, self._temp(), want_grad=False)[0]
+
+    def hamiltonian(self, x, v, aux=None):
+        return self.energy(x) + self.kinetic(v)
+
+    def grad_energy(self, x, aux=None):
+        """:241-242 -- closed form of the reference's tf.gradients."""
+        return self._target.energy_grad(x, self._temp())[1]
+
+    def _plan(self):
+        p = _lib.SmallPlan(x_dim=self.x_dim, trajectory_length=self.trajectory_length, hmc=int(bool(self.hmc)),
+                           eps=float(self.eps), reserved=0., masks=self.mask.data_ptr(),
+                           target=self._target.struct(self._temp()), num_nodes=0)
+        if not self.hmc:
+            p.xnet, p.vnet = self.XNet.pack(), self.VNet.pack()
+            p.num_nodes = p.xnet.H
+        return p
+
+    def _normal(self, shape):
+        out = torch.empty(shape, dtype=torch.float32, device=self._device)
+        _lib.check(_lib.lib().l2hmc_fill_normal(out.data_ptr(), out.numel(), self._seed, self._draws,
+                                                _lib.stream_ptr()))
+        self._draws += 1
+        return out
+
+    def _run(self, x, init_v, backward, log_jac):
+        x = _lib.as_dev(x, self._device).reshape(-1, self.x_dim)
+        v = _lib.as_dev(init_v, self._device) if init_v is not None else self._normal(tuple(x.shape))
+        rows = x.shape[0]
+        X, V = torch.empty_like(x), torch.empty_like(x)
+        lj = torch.empty(rows, dtype=torch.float32, device=x.device)
+        p = torch.empty_like(lj)
+        dirs = torch.full((rows,), 1, dtype=torch.int32, device=x.device) if backward else None
+        plan = self._plan()
+        _lib.check(_lib.lib().l2hmc_small_trajectory(
+            C.byref(plan), x.data_ptr(), _lib.dev_ptr(v, name="init_v"), _lib.dev_ptr(dirs, torch.int32), rows,
+            X.data_ptr(), V.data_ptr(), lj.data_ptr(), p.data_ptr(), _lib.stream_ptr()))
+        return (X, V, lj) if log_jac else (X, V, p)
+
+    def forward(self, x, init_v=None, aux=None, log_path=False, log_jac=False):
+        """:255-281."""
+        if aux is not None:
+            raise NotImplementedError("aux inputs are only used by the out-of-scope VAE scripts")
+        return self._run(x, init_v, False, log_jac)
+
+    def backward(self, x, init_v=None, aux=None, log_jac=False):
+        """:283-310."""
+        if aux is not None:
+            raise NotImplementedError("aux inputs are only used by the out-of-scope VAE scripts")
+        return self._run(x, init_v, True, log_jac)
+
+    def p_accept(self, x0, v0, x1, v1, log_jac, aux=None):
+        """:312-319."""
+        e_new, e_old = self.hamiltonian(x1, v1), self.hamiltonian(x0, v0)
+        lj = _lib.as_dev(log_jac, self._device)
+        p = torch.empty_like(e_old)
+        _lib.check(_lib.lib().l2hmc_accept_prob(e_old.data_ptr(), e_new.data_ptr(), lj.data_ptr(), p.numel(),
+                                                p.data_ptr(), _lib.stream_ptr()))
+        return p

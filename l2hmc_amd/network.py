@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's S/T/Q network classes.
+
+Same constructor keywords, layer attribute names and call convention as
+  l2hmc/network/generic_net.py:20-161 (GenericNet, _custom_dense)
+  l2hmc/utils/network.py:89-114, 359-454 (`network` factory, Linear, ScaleTanh)
+Weights are stored in the reference's layout (Dense kernel = [in, out]) on the
+device; `pack()` produces the k-contiguous buffers the HIP kernels read
+(include/l2hmc_hip.h, struct l2hmc_dense_net)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _trunc_normal(rng, shape, std):
+    out = rng.standard_normal(shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * std).astype(np.float32)
+
+
+class Dense:
+    """tf.keras.layers.Dense stand-in: `kernel` [in, out], `bias` [out]
+    (generic_net.py:149-161: variance_scaling(factor*2, FAN_IN, truncated normal), zero bias)."""
+
+    def __init__(self, fan_in, units, factor=1., name=None, rng=None, device=None):
+        rng = rng if rng is not None else np.random
+        std = np.sqrt(1.3 * (factor * 2.) / fan_in)
+        self.name = name
+        self.kernel = torch.from_numpy(_trunc_normal(rng, (fan_in, units), std)).to(device)
+        self.bias = torch.zeros(units, dtype=torch.float32, device=device)
+
+    @property
+    def variables(self):
+        return [self.kernel, self.bias]
+
+
+class _DenseSTQ:
+    """Shared machinery: three input layers, one hidden layer, three heads."""
+    q_tanh = 0
+    _layer_names = ()   # (first-input, second-input, time, hidden, S, T, Q)
+    _coeff_names = ()
+
+    def _layers(self):
+        return [getattr(self, n) for n in self._layer_names]
+
+    @property
+    def variables(self):
+        out = []
+        for layer in self._layers():
+            out.extend(layer.variables)
+        out.extend(getattr(self, n) for n in self._coeff_names)
+        return out
+
+    trainable_variables = variables
+
+    def state_dict(self):
+        d = {}
+        for n in self._layer_names:
+            d[n + "/W"] = getattr(self, n).kernel
+            d[n + "/b"] = getattr(self, n).bias
+        for n in self._coeff_names:
+            d[n] = getattr(self, n)
+        return d
+
+    def load_state(self, state):
+        """Set weights from {name: array}; keys as state_dict() (the oracle uses the same)."""
+        dev = self._device
+        for n in self._layer_names:
+            layer = getattr(self, n)
+            W = _lib.as_dev(state[n + "/W"], dev)
+            b = _lib.as_dev(state[n + "/b"], dev)
+            if W.shape != layer.kernel.shape or b.shape != layer.bias.shape:
+                raise ValueError(f"{n}: shape {tuple(W.shape)} != {tuple(layer.kernel.shape)}")
+            layer.kernel, layer.bias = W, b
+        for n in self._coeff_names:
+            c = _lib.as_dev(state[n], dev).reshape(1, -1)
+            if c.shape != getattr(self, n).shape:
+                raise ValueError(f"{n}: bad shape {tuple(c.shape)}")
+            setattr(self, n, c)
+        self._packed = None
+
+    def save_weights(self, path):
+        """gauge_model.py:549-554 calls .save_weights on position_fn / momentum_fn."""
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.state_dict().items()})
+
+    def load_weights(self, path):
+        with np.load(path if str(path).endswith(".npz") else str(path) + ".npz") as f:
+            self.load_state({k: f[k] for k in f.files})
+
+    # ---- packing for the HIP kernels
+    def pack(self):
+        """(struct l2hmc_dense_net, keep-alive tensors); rebuilt after load_state()."""
+        if self._packed is None:
+            la, lb, lt, lh, ls, ltr, lq = self._layers()
+            cs, cq = (getattr(self, n) for n in self._coeff_names)
+            Ka, Kb, H, D = la.kernel.shape[0], lb.kernel.shape[0], lh.kernel.shape[0], ls.kernel.shape[1]
+            bufs = dict(
+                w1_t=torch.cat([la.kernel, lb.kernel], dim=0).t().contiguous(),         # [H][Ka+Kb]
+                wt=lt.kernel.contiguous(),                                               # [2][H]
+                b1=(la.bias + lb.bias + lt.bias).contiguous(),
+                wh_t=lh.kernel.t().contiguous(),                                          # [H][H] (out, in)
+                bh=lh.bias.contiguous(),
+                whd_t=torch.stack([ls.kernel.t(), ltr.kernel.t(), lq.kernel.t()]).contiguous(),  # [3][D][H]
+                bhd=torch.stack([ls.bias, ltr.bias, lq.bias]).contiguous(),               # [3][D]
+                coeff_s=cs.reshape(-1).contiguous(), coeff_q=cq.reshape(-1).contiguous())
+            st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0,
+                               **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
+            self._packed = (st, bufs)
+        return self._packed[0]
+
+    # ---- standalone evaluation: (S, T, Q) = net([a, b, t])
+    def __call__(self, inputs):
+        a, b, t = inputs[0], inputs[1], inputs[2]
+        a = _lib.as_dev(a, self._device).reshape(a.shape[0], -1)
+        b = _lib.as_dev(b, self._device).reshape(b.shape[0], -1)
+        t = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 2)
+        tc, ts = float(t[0, 0]), float(t[0, 1])
+        st = self.pack()
+        rows = a.shape[0]
+        S, T, Q = (torch.empty(rows, st.D, dtype=torch.float32, device=a.device) for _ in range(3))
+        L = _lib.lib()
+        ws, nb = self._ws.get(L.l2hmc_stq_ws_bytes(rows, st.H), a.device)
+        _lib.check(L.l2hmc_stq_dense(C.byref(st), _lib.dev_ptr(a, name="a"), _lib.dev_ptr(b, name="b"), None,
+                                     tc, ts, rows, S.data_ptr(), T.data_ptr(), Q.data_ptr(), ws, nb,
+                                     _lib.stream_ptr()))
+        return S, T, Q
+
+    call = __call__
+
+
+class GenericNet(_DenseSTQ):
+    """generic_net.py:20-146.  kwargs: x_dim, num_hidden, factor, name_scope, links_shape."""
+    q_tanh = 0
+    _layer_names = ("v_layer", "x_layer", "t_layer", "h_layer", "scale_layer", "translation_layer",
+                    "transformation_layer")
+    _coeff_names = ("coeff_scale", "coeff_transformation")
+
+    def __init__(self, model_name='GenericNet', rng=None, device=None, **kwargs):
+        self.name = model_name
+        for key, val in kwargs.items():
+            setattr(self, key, val)
+        if getattr(self, "name_scope", None) is None:
+            self.name_scope = model_name
+        self._device = device or torch.device("cuda", torch.cuda.current_device())
+        dev, D, H = self._device, int(self.x_dim), int(self.num_hidden)
+        # creation order follows generic_net.py:39-90 (it fixes the RNG stream order)
+        self.x_layer = Dense(D, H, self.factor / 3., 'x_layer', rng, dev)
+        self.v_layer = Dense(D, H, 1. / 3., 'v_layer', rng, dev)
+        self.t_layer = Dense(2, H, 1. / 3., 't_layer', rng, dev)
+        self.h_layer = Dense(H, H, 1., 'h_layer', rng, dev)
+        self.scale_layer = Dense(H, D, 0.001, 'scale_layer', rng, dev)
+        self.coeff_scale = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        self.translation_layer = Dense(H, D, 0.001, 'translation_layer', rng, dev)
+        self.transformation_layer = Dense(H, D, 0.001, 'transformation_layer', rng, dev)
+        self.coeff_transformation = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        self._packed = None
+        self._ws = _lib.Workspace()
+
+
+class MLPNet(_DenseSTQ):
+    """utils/network.py:89-114: what `network(x_dim, scope, factor, num_nodes)` returns.
+    Callable on [a, b, t, aux]; aux is ignored (the `lambda _: 0.` slot)."""
+    q_tanh = 1
+    _layer_names = ("embed_1", "embed_2", "embed_3", "linear_1", "linear_s", "linear_t", "linear_f")
+    _coeff_names = ("scale_s", "scale_f")
+
+    def __init__(self, x_dim, scope, factor, num_nodes=50, rng=None, device=None):
+        self.name = self.scope = scope
+        self.x_dim, self.num_nodes, self.factor = int(x_dim), int(num_nodes), factor
+        self._device = device or torch.device("cuda", torch.cuda.current_device())
+        dev, D, H = self._device, self.x_dim, self.num_nodes
+        self.embed_1 = Dense(D, H, 1. / 3., 'embed_1', rng, dev)
+        self.embed_2 = Dense(D, H, factor / 3., 'embed_2', rng, dev)
+        self.embed_3 = Dense(2, H, 1. / 3., 'embed_3', rng, dev)
+        self.linear_1 = Dense(H, H, 1., 'linear_1', rng, dev)
+        self.linear_s = Dense(H, D, 0.001, 'linear_s', rng, dev)
+        self.scale_s = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        self.linear_t = Dense(H, D, 0.001, 'linear_t', rng, dev)
+        self.linear_f = Dense(H, D, 0.001, 'linear_f', rng, dev)
+        self.scale_f = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        self._packed = None
+        self._ws = _lib.Workspace()
+
+    def __call__(self, inputs):
+        raise NotImplementedError(
+            "MLPNet is evaluated inside l2hmc_small_trajectory (one fused kernel per trajectory); "
+            "its widths are below the MFMA path's 32-multiple requirement")
+
+
+def network(x_dim, scope, factor, num_nodes=50, rng=None, device=None):
+    """utils/network.py:89 -- the `net_factory` callers hand to Dynamics."""
+    return MLPNet(x_dim, scope, factor, num_nodes, rng=rng, device=device)
