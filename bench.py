@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Throughput of the L2HMC hot path on MI355X: chain-leapfrog-steps per second.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one `apply_transition` (dynamics/gauge_dynamics.py:195-259) over a
+batch of synthetic chains: momenta, direction coin and MH uniform drawn on the
+device, BOTH directions integrated (as the reference does), accept/reject,
+wrap to [0, 2pi) and per-step observables -- all resident in HBM.  Workload:
+BASELINE.json configs[2], the configuration its metric is quoted on (2D U(1)
+8x8, beta 2.0, batch 2048 per GPU, 10 leapfrog steps, GenericNet H=512, fp32).
+
+N > 1 (launched through torch.distributed.run, one rank per GPU): chains are
+independent, so every rank integrates its own 2048 chains (weak scaling) and
+the only exchange is one small RCCL all-reduce of the per-step scalar sums
+(accept probability, |dQ|, count), issued on a side stream.
+
+Prints ONE JSON line (rank 0).  `value` counts USEFUL chain-leapfrog steps
+(B*N_LF per transition); the executed count is twice that and is what the
+roofline FLOPs use.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L, BETA, EPS, N_LF, BATCH, HID_MULT = 8, 2.0, 0.25, 10, 2048, 4
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+
+
+def net_macs(D, H):
+    """generic net MACs per call per chain = 2DH + 2H + H^2 + 3HD."""
+    return 2 * D * H + 2 * H + H * H + 3 * H * D
+
+
+def build_dynamics(batch, both_directions=True):
+    from tests import helpers as H
+    xp, vp = H.gauge_weights(L, L, seed=106, regime="init", hidden_mult=HID_MULT)
+    masks = H.gauge_oracle(L, L, N_LF, EPS, xp, vp).mask
+    dyn = H.gauge_hip(L, L, N_LF, EPS, xp, vp, masks, batch, both_directions=both_directions)
+    return dyn, xp, vp, masks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--selected-only", action="store_true",
+                    help="integrate only the direction each chain's coin selects (not the reference's work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from l2hmc_amd import _lib, u1_observables
+    from l2hmc_amd.dist import StepStats
+    dev = torch.device("cuda", local_rank)
+    both = not args.selected_only
+    dyn, xp, vp, masks = build_dynamics(BATCH, both)
+    dyn._seed = 1000 + rank                       # independent chains per rank
+    D = 2 * L * L
+    x = torch.empty(BATCH, D, device=dev)
+    _lib.check(_lib.lib().l2hmc_fill_uniform(x.data_ptr(), x.numel(), 103 + rank, 0, _lib.stream_ptr()))
+    x.mul_(2 * np.pi)                             # hot start, lattice.py:131-135
+    stats = StepStats(dev, dist)
+
+    def step(x):
+        x_prop, v_prop, p, x_out = dyn(x, BETA)
+        q_old = u1_observables(x, L, L)["top_charge"]
+        x_new = torch.remainder(x_out, 2 * np.pi)              # gauge_model.py:1180
+        obs = u1_observables(x_new, L, L)                      # per-step observables, :256-266
+        stats.push(p, torch.abs(obs["top_charge"] - q_old))    # one fused all-reduce per step
+        return x_new
+
+    for _ in range(args.warmup):
+        x = step(x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = step(x)
+    stats.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    accept_rate = stats.mean_accept()
+
+    useful = world * BATCH * N_LF * args.steps
+    value = useful / dt
+    out = {
+        "metric": "leapfrog-steps/sec (whole node), 8x8 U(1) batch 2048, 10 LF",
+        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "U(1) 8x8 lattice, beta=2.0, batch 2048 per GPU, 10 LF steps, GenericNet H=512 "
+                               "(BASELINE.json configs[2])",
+                   "global_batch": world * BATCH, "lattice": [L, L], "num_steps": N_LF, "eps": EPS, "beta": BETA,
+                   "directions_integrated": 2 if both else 1,
+                   "executed_chain_lf_per_step": (2 if both else 1) * BATCH * N_LF * world,
+                   "parallelism": f"chains sharded over {world} GPU(s), weights replicated",
+                   "mean_accept_prob": accept_rate},
+    }
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream ----
+    if rank == 0 and not args.no_roofline:
+        Lh = _lib.lib()
+        rows = (2 if both else 1) * BATCH
+        Hd = HID_MULT * D
+        per_class = {}
+        for cls, name, flops in ((1, "gemm_relu_kernel<64,1> (first layer)", 2.0 * rows * Hd * 2 * D),
+                                 (2, "gemm_relu_kernel<64,2> (hidden layer)", 2.0 * rows * Hd * Hd),
+                                 (3, "heads_kernel (S/T/Q + update)", 2.0 * rows * 3 * D * Hd)):
+            _lib.check(Lh.l2hmc_profile_begin(cls))
+            xs = x
+            for _ in range(min(args.steps, 10)):
+                xs = step(xs)
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))
+            per_class[cls] = dict(kernel=name, launches=n.value, avg_us=1e3 * ms.value / max(n.value, 1),
+                                  flops_per_launch=flops,
+                                  tflops=flops / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0)
+        dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
+        out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
+                           "algorithmic_flops_per_launch": dom["flops_per_launch"],
+                           "all_kernels": list(per_class.values()),
+                           "whole_step_tflops": (2 if both else 1) * BATCH * N_LF * 8 * net_macs(D, Hd)
+                           / (dt / args.steps) / 1e12}
+
+    # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import time_cpu_baseline
+        sample_b = 256
+        cb = time_cpu_baseline(L, L, N_LF, EPS, BETA, sample_b, xp, vp, masks, budget_s=15.0)
+        out["cpu_baseline"] = {"value": cb["value"], "unit": "chain-leapfrog-steps/s", "cores": cb["cores"],
+                               "kind": "port",
+                               "sample": f"{cb['calls']} timed apply_transition calls (both directions) on "
+                                         f"{sample_b} of the 2048 chains, same lattice/net/LF config, torch-CPU fp32, "
+                                         f"median {cb['seconds']:.3f} s per call"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

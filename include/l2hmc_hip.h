@@ -97,7 +97,16 @@ typedef struct l2hmc_dense_net {
   const float* coeff_q;
   int32_t q_tanh;
   int32_t reserved;
+  const float* packed; /* optional: l2hmc_dense_pack() image for the fused trajectory kernel, or NULL */
 } l2hmc_dense_net;
+
+/* Fragment-ordered copy of (w1_t, wh_t, whd_t) for the whole-trajectory kernel:
+ * [wave][k-chunk][n-tile][lane][4] per layer, so every B-operand load of a wave is
+ * one contiguous 1 KiB read.  pack_bytes() is 0 when the shape has no fused kernel
+ * (then leave .packed NULL: the layer-by-layer kernels are used).  Re-pack after
+ * every weight update. */
+size_t l2hmc_dense_pack_bytes(const l2hmc_dense_net* net);
+int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc_stream_t stream);
 
 /* scratch for one net evaluation on `rows` rows: two [rows][H] activations */
 size_t l2hmc_stq_ws_bytes(int64_t rows, int32_t H);
@@ -139,12 +148,13 @@ int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const flo
  * Lattice integrator: gauge_dynamics.py:412-483 (_forward_lf/_backward_lf),
  * :261-313 (transition_kernel), :195-259 (apply_transition).
  * ------------------------------------------------------------------------ */
+#define L2HMC_PLAN_LAYERED 1
 typedef struct l2hmc_gauge_plan {
   int32_t T, X;            /* lattice extents; D = 2*T*X */
   int32_t num_steps;       /* N_LF */
   int32_t hmc;             /* 1: S=T=Q=0 (gauge_dynamics.py:102-108), nets ignored */
   float eps;
-  float reserved;
+  int32_t flags;           /* L2HMC_PLAN_LAYERED: never use the fused whole-trajectory kernel */
   const float* masks;      /* [num_steps][D] 0/1, gauge_dynamics.py:651-661 */
   l2hmc_dense_net xnet;    /* position_fn */
   l2hmc_dense_net vnet;    /* momentum_fn */
@@ -222,6 +232,17 @@ int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const 
  * ------------------------------------------------------------------------ */
 int l2hmc_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream);
 int l2hmc_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): time every launch of one kernel
+ * class with HIP events recorded on the launch stream.  begin() arms it (0
+ * disarms), end() synchronises the recorded events and returns the summed
+ * kernel time and launch count.  Not thread-safe; not for use while capturing.
+ *   1 = first dense layer   2 = hidden dense layer   3 = heads (+update)
+ *   4 = u1_action_force     5 = fused whole-trajectory kernel
+ * ------------------------------------------------------------------------ */
+int l2hmc_profile_begin(int32_t kernel_class);
+int l2hmc_profile_end(double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

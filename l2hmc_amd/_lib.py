@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
+PLAN_LAYERED = 1
 
 
 class DenseNet(C.Structure):
@@ -22,12 +23,12 @@ class DenseNet(C.Structure):
                 ("w1_t", c_float_p), ("wt", c_float_p), ("b1", c_float_p), ("wh_t", c_float_p),
                 ("bh", c_float_p), ("whd_t", c_float_p), ("bhd", c_float_p),
                 ("coeff_s", c_float_p), ("coeff_q", c_float_p),
-                ("q_tanh", C.c_int32), ("reserved", C.c_int32)]
+                ("q_tanh", C.c_int32), ("reserved", C.c_int32), ("packed", c_float_p)]
 
 
 class GaugePlan(C.Structure):
     _fields_ = [("T", C.c_int32), ("X", C.c_int32), ("num_steps", C.c_int32), ("hmc", C.c_int32),
-                ("eps", C.c_float), ("reserved", C.c_float), ("masks", c_float_p),
+                ("eps", C.c_float), ("flags", C.c_int32), ("masks", c_float_p),
                 ("xnet", DenseNet), ("vnet", DenseNet)]
 
 
@@ -52,6 +53,8 @@ _PROTOS = {
     "l2hmc_kinetic_energy": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "l2hmc_stq_ws_bytes": (_SZ, [_I64, _I32]),
     "l2hmc_stq_dense": (C.c_int, [C.POINTER(DenseNet), _P, _P, _P, _F, _F, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "l2hmc_dense_pack_bytes": (_SZ, [C.POINTER(DenseNet)]),
+    "l2hmc_dense_pack": (C.c_int, [C.POINTER(DenseNet), _P, _P]),
     "l2hmc_lf_update_v": (C.c_int, [_P, _P, _P, _P, _P, _F, _I32, _I64, _I32, _P, _P, _P]),
     "l2hmc_lf_update_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I32, _I64, _I32, _P, _P, _P]),
     "l2hmc_accept_prob": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
@@ -65,6 +68,8 @@ _PROTOS = {
                                          _P, _P, _P, _SZ, _P]),
     "l2hmc_mog_energy_grad": (C.c_int, [C.POINTER(MogTarget), _P, _I64, _P, _P, _P]),
     "l2hmc_small_trajectory": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "l2hmc_profile_begin": (C.c_int, [_I32]),
+    "l2hmc_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "l2hmc_fill_normal": (C.c_int, [_P, _I64, _U64, _U64, _P]),
     "l2hmc_fill_uniform": (C.c_int, [_P, _I64, _U64, _U64, _P]),
 }

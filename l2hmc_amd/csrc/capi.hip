@@ -1,6 +1,8 @@
 // Error plumbing of the C ABI + the counter-based RNG.
 #include "common.h"
 #include <string.h>
+#include <utility>
+#include <vector>
 
 namespace l2hmc {
 
@@ -11,6 +13,28 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------------
+// per-kernel-class event timing (host side only; never active unless asked)
+// ---------------------------------------------------------------------
+static int g_prof_cls = kProfNone;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+
+void prof_before(int cls, hipStream_t stream) {
+  if (cls != g_prof_cls) return;
+  if (g_prof_used == g_prof_events.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_prof_events.emplace_back(a, b);
+  }
+  (void)hipEventRecord(g_prof_events[g_prof_used].first, stream);
+}
+
+void prof_after(int cls, hipStream_t stream) {
+  if (cls != g_prof_cls) return;
+  if (g_prof_used < g_prof_events.size()) (void)hipEventRecord(g_prof_events[g_prof_used++].second, stream);
 }
 
 // ---------------------------------------------------------------------
@@ -86,6 +110,32 @@ using namespace l2hmc;
 
 extern "C" int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
 extern "C" const char* l2hmc_last_error(void) { return g_err; }
+
+extern "C" int l2hmc_profile_begin(int32_t kernel_class) {
+  L2HMC_REQUIRE(kernel_class >= kProfNone && kernel_class <= kProfFused, "profile_begin: unknown class %d",
+                kernel_class);
+  g_prof_cls = kernel_class;
+  g_prof_used = 0;
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_profile_end(double* total_ms, int64_t* launches) {
+  g_prof_cls = kProfNone;
+  double tot = 0.0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof_events[i].second) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second) != hipSuccess) {
+      set_error("profile_end: event query failed");
+      return L2HMC_ERR_HIP;
+    }
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)g_prof_used;
+  g_prof_used = 0;
+  return L2HMC_OK;
+}
 
 extern "C" int l2hmc_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, l2hmc_stream_t stream) {
   return launch_fill<true>(out, n, seed, offset, (hipStream_t)stream);

@@ -35,6 +35,12 @@ static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Optional per-kernel-class timing with HIP events on the launch stream
+// (l2hmc_profile_begin/_end; used by bench.py's roofline pass, off otherwise).
+enum ProfClass { kProfNone = 0, kProfGemmL1 = 1, kProfGemmL2 = 2, kProfHeads = 3, kProfU1 = 4, kProfFused = 5 };
+void prof_before(int cls, hipStream_t stream);
+void prof_after(int cls, hipStream_t stream);
+
 // sum across the 64 lanes of a wave; every lane gets the total (fixed tree => deterministic)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

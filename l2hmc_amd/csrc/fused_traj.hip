@@ -1,0 +1,473 @@
+// Whole-trajectory persistent kernel for the lattice integrator (gfx950).
+//
+// One launch integrates ALL leapfrog steps of
+//   l2hmc/dynamics/gauge_dynamics.py:261-313 (transition_kernel) with
+//   :412-483 (_forward_lf/_backward_lf), :486-590 (sub-updates), :592-609 (accept
+//   prob), network/generic_net.py:129-146 (S/T/Q nets) and the U(1) force
+//   (:698-709 over lattice/lattice.py:337-362)
+// for a tile of 16 chain-rows per workgroup.  Chains are independent and the
+// plaquette stencil is local to a chain, so a workgroup never talks to another
+// one: x, v, force, both hidden activations and the log-det sums live in LDS
+// for the whole trajectory (read from / written to HBM exactly once), and the
+// only steady-state traffic is the weight stream.
+//
+// Why 16 rows: rows / 256 CUs = 16 at the benchmark shape (2 directions x 2048
+// chains), which is exactly one 16x16x4 fp32 MFMA tile in M.  Every CU then
+// streams every weight once per network call: (2DH + H^2 + 3DH) * 4 B = 2.36 MB
+// per 18.9 MFLOP of MFMA work, i.e. ~77 GB/s per CU at the fp32 MFMA peak --
+// the L2 -> CU fabric roofline and the MFMA roofline coincide.
+// Weights are therefore pre-packed (l2hmc_dense_pack) into the exact order a
+// wave consumes them -- [wave][k-chunk][n-tile][lane][4] -- so each B-fragment
+// load is one fully coalesced 1 KiB global_load_dwordx4 straight into VGPRs (no
+// LDS round trip: a wave's columns are not shared with other waves), double
+// buffered one k-chunk (16 k) ahead.  The A operand (16 rows of activations) is
+// shared by the 4 waves and read from LDS with conflict-free ds_read_b128
+// (row stride = K + 8 floats).
+#include "stq_dense.h"
+#include <math.h>
+
+namespace l2hmc {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kFM = 16;          // rows per workgroup
+constexpr int kFThreads = 256;   // 4 waves; wave w owns output columns [w*N/4, (w+1)*N/4)
+
+template <int D, int H>
+struct FusedCfg {
+  static constexpr int SX = D + 8;             // LDS row stride of x / v / second-input rows
+  static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
+  static constexpr int NT1 = H / 64;           // 16-column tiles per wave, layers 1 and 2
+  static constexpr int NTH = D / 64;           // tiles per wave per head
+  static constexpr int KC1 = 2 * D / 16;       // k-chunks (16 k each), layer 1
+  static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
+  static constexpr size_t P1 = (size_t)2 * D * H;   // packed floats per section
+  static constexpr size_t P2 = (size_t)H * H;
+  static constexpr size_t PH = (size_t)3 * D * H;
+  // per-net constants kept in LDS: b1[H] wt[2H] bh[H] bhd[3D] exp(cs)[D] exp(cq)[D]
+  static constexpr int NC = 4 * H + 5 * D;
+  static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
+                                    2 * D /*masks*/ + 4 * kFM /*ldw*/ + kFM /*dir*/;
+};
+
+// ---------------------------------------------------------------------------
+// weight packing (device side, once per weight update)
+// ---------------------------------------------------------------------------
+__global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out) {
+  const int D = n.D, H = n.H, K1 = n.Ka + n.Kb;
+  const size_t P1 = (size_t)K1 * H, P2 = (size_t)H * H, PH = (size_t)3 * D * H;
+  const int NT1 = H / 64, NTH = D / 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P1 + P2 + PH;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t rest;
+    float val;
+    if (i < P1 + P2) {
+      const bool first = i < P1;
+      const int K = first ? K1 : H;
+      rest = (first ? i : i - P1) >> 8;               // ((w * KC + kc) * NT1 + t)
+      const int t = (int)(rest % NT1);
+      rest /= NT1;
+      const int KC = K / 16;
+      const int kc = (int)(rest % KC), w = (int)(rest / KC);
+      const int col = (w * NT1 + t) * 16 + (lane & 15);
+      const int k = kc * 16 + (lane >> 4) * 4 + j;
+      val = first ? n.w1_t[(size_t)col * K1 + k] : n.wh_t[(size_t)col * H + k];
+    } else {
+      rest = (i - P1 - P2) >> 8;                      // (((w * KC2 + kc) * 3 + hd) * NTH + t)
+      const int t = (int)(rest % NTH);
+      rest /= NTH;
+      const int hd = (int)(rest % 3);
+      rest /= 3;
+      const int KC = H / 16;
+      const int kc = (int)(rest % KC), w = (int)(rest / KC);
+      const int col = w * (D / 4) + t * 16 + (lane & 15);
+      const int k = kc * 16 + (lane >> 4) * 4 + j;
+      val = n.whd_t[((size_t)hd * D + col) * H + k];
+    }
+    out[i] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// streaming GEMM core: acc[t] += A(16 x 16*NKC) . Wpacked, one wave, NT tiles
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void mfma_block(const f32x4 a, const f32x4 (&b)[NT], f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[t][e], acc[t], 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restrict__ wp, int kc) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
+}
+
+// wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc.
+template <int NT, int NKC, typename AF>
+__device__ __forceinline__ void stream_layer(const float* __restrict__ wp, AF afrag, f32x4 (&acc)[NT]) {
+  static_assert(NKC % 2 == 0, "k-chunks are consumed in pairs");
+  f32x4 b0[NT], b1[NT];
+  load_frags<NT>(b0, wp, 0);
+  load_frags<NT>(b1, wp, 1);
+#pragma nounroll
+  for (int kc = 0; kc < NKC; kc += 2) {
+    f32x4 a = afrag(kc);
+    mfma_block<NT>(a, b0, acc);
+    if (kc + 2 < NKC) load_frags<NT>(b0, wp, kc + 2);
+    a = afrag(kc + 1);
+    mfma_block<NT>(a, b1, acc);
+    if (kc + 3 < NKC) load_frags<NT>(b1, wp, kc + 3);
+  }
+}
+
+struct FusedArgs {
+  int T, X, num_steps, step_begin, step_end;
+  float eps, beta;
+  const float* masks;                    // [num_steps][D]
+  l2hmc_dense_net xnet, vnet;            // .packed must be set
+  const float* x0; const float* v0;      // [rows][D]
+  const int* dir;                        // [rows] or NULL
+  int64_t rows;
+  float* x_out; float* v_out;            // [rows][D]
+  float* logdet;                         // [rows] or NULL; written (=) or accumulated (+=)
+  int logdet_accumulate;
+  float* p_accept;                       // [rows] or NULL
+};
+
+template <int D, int H>
+__global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p) {
+  using Cfg = FusedCfg<D, H>;
+  constexpr int SX = Cfg::SX, SH = Cfg::SH, NT1 = Cfg::NT1, NTH = Cfg::NTH;
+  constexpr int sites = D / 2;
+  constexpr int SP = sites + 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                         // [16][SX] position
+  float* vs = xs + kFM * SX;               // [16][SX] momentum
+  float* gs = vs + kFM * SX;               // [16][SX] second net input: force, or keep (.) x
+  float* h1 = gs + kFM * SX;               // [16][SH]
+  float* h2 = h1 + kFM * SH;               // [16][SH]
+  float* cx = h2 + kFM * SH;               // XNet constants [NC]
+  float* cv = cx + Cfg::NC;                // VNet constants [NC]
+  float* sp = cv + Cfg::NC;                // [16][SP] sin P
+  float* skm = sp + kFM * SP;              // [2][D]  masks of this step: forward row, backward row
+  float* ldw = skm + 2 * D;                // [4][16] log-det partial sums per wave
+  int* sdir = reinterpret_cast<int*>(ldw + 4 * kFM);   // [16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int64_t row0 = (int64_t)blockIdx.x * kFM;
+  const int nrow = (int)min((int64_t)kFM, p.rows - row0);
+  const float eps = p.eps;
+
+  // ---- stage chain state and constants ------------------------------------
+  for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
+    const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (rr < nrow) {
+      xv = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + rr) * D + c4);
+      vv = *reinterpret_cast<const f32x4*>(p.v0 + (row0 + rr) * D + c4);
+    }
+    *reinterpret_cast<f32x4*>(xs + rr * SX + c4) = xv;
+    *reinterpret_cast<f32x4*>(vs + rr * SX + c4) = vv;
+  }
+  auto load_consts = [&](const l2hmc_dense_net& n, float* c) {
+    for (int i = tid; i < H; i += kFThreads) {
+      c[i] = n.b1[i];
+      c[H + i] = n.wt[i];
+      c[2 * H + i] = n.wt[H + i];
+      c[3 * H + i] = n.bh[i];
+    }
+    for (int i = tid; i < 3 * D; i += kFThreads) c[4 * H + i] = n.bhd[i];
+    for (int i = tid; i < D; i += kFThreads) {
+      c[4 * H + 3 * D + i] = expf(n.coeff_s[i]);
+      c[4 * H + 4 * D + i] = expf(n.coeff_q[i]);
+    }
+  };
+  load_consts(p.xnet, cx);
+  load_consts(p.vnet, cv);
+  if (tid < kFM) sdir[tid] = (p.dir && tid < nrow) ? p.dir[row0 + tid] : 0;
+  if (tid < 4 * kFM) ldw[tid] = 0.f;
+  __syncthreads();
+
+  int dirr[4];                        // direction of the 4 rows this lane owns in a C fragment
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dirr[e] = sdir[q * 4 + e];
+
+  // ---- chain-local passes: 16 threads per chain -----------------------------
+  const int fc = tid >> 4, fl = tid & 15;          // chain, lane-in-chain
+  const int T = p.T, X = p.X;
+  // force (beta * dS/dx) into gs; returns this chain's action (all 16 lanes of the chain)
+  auto force_pass = [&]() -> float {
+    const float* xc = xs + fc * SX;
+    float act = 0.f;
+    for (int s = fl; s < sites; s += 16) {
+      const int i = s / X, j = s - i * X;
+      const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
+      const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
+      float sn, cs;
+      sincosf(P, &sn, &cs);
+      sp[fc * SP + s] = sn;
+      act += 1.f - cs;
+    }
+    act += __shfl_xor(act, 8, 64);
+    act += __shfl_xor(act, 4, 64);
+    act += __shfl_xor(act, 2, 64);
+    act += __shfl_xor(act, 1, 64);
+    __syncthreads();
+    float* gc = gs + fc * SX;
+    const float* spc = sp + fc * SP;
+    for (int s = fl; s < sites; s += 16) {
+      const int i = s / X, j = s - i * X;
+      const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
+      const float sP = spc[s];
+      gc[2 * s] = p.beta * (sP - spc[i * X + jm]);
+      gc[2 * s + 1] = p.beta * (-sP + spc[im * X + j]);
+    }
+    __syncthreads();
+    return act;
+  };
+  auto kinetic_pass = [&]() -> float {
+    const float* vc = vs + fc * SX;
+    float k = 0.f;
+    for (int d = fl; d < D; d += 16) k += vc[d] * vc[d];
+    k += __shfl_xor(k, 8, 64);
+    k += __shfl_xor(k, 4, 64);
+    k += __shfl_xor(k, 2, 64);
+    k += __shfl_xor(k, 1, 64);
+    return 0.5f * k;
+  };
+
+  const float act0 = force_pass();     // also leaves the force of x0 in gs
+  const float kin0 = kinetic_pass();
+
+  // ---- one network evaluation + fused sub-update ------------------------------
+  // in1: first input rows (LDS, stride SX); second input is always gs.
+  // mode 1: momentum update (uses gs as the force), mode 2: position update with keep masks.
+  auto net_update = [&](const l2hmc_dense_net& net, const float* cn, const float* in1, int mode, int sub,
+                        const float (&tcr)[4], const float (&tsr)[4]) {
+    const float* pk = net.packed;
+    // ----- layer 1
+    {
+      f32x4 acc[NT1];
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
+      const float* a1 = in1 + r * SX + q * 4;
+      const float* a2 = gs + r * SX + q * 4;
+      stream_layer<NT1, Cfg::KC1>(
+          wp,
+          [&](int kc) {
+            const float* src = kc < D / 16 ? a1 + kc * 16 : a2 + (kc - D / 16) * 16;
+            return *reinterpret_cast<const f32x4*>(src);
+          },
+          acc);
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+        const int col = (wave * NT1 + t) * 16 + r;
+        const float b = cn[col], w0 = cn[H + col], w1 = cn[2 * H + col];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          h1[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b + (tcr[e] * w0 + tsr[e] * w1), 0.f);
+      }
+    }
+    __syncthreads();
+    // ----- layer 2
+    {
+      f32x4 acc[NT1];
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
+      const float* a = h1 + r * SH + q * 4;
+      stream_layer<NT1, Cfg::KC2>(
+          wp, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+        const int col = (wave * NT1 + t) * 16 + r;
+        const float b = cn[3 * H + col];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h2[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b, 0.f);
+      }
+    }
+    __syncthreads();
+    // ----- heads + update
+    {
+      f32x4 acc[3 * NTH];
+#pragma unroll
+      for (int t = 0; t < 3 * NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
+      const float* a = h2 + r * SH + q * 4;
+      stream_layer<3 * NTH, Cfg::KC2>(
+          wp, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+      float ld[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* bhd = cn + 4 * H;
+      const float* es = bhd + 3 * D;
+      const float* eq = es + D;
+#pragma unroll
+      for (int t = 0; t < NTH; ++t) {
+        const int col = wave * (D / 4) + t * 16 + r;
+        const float b_s = bhd[col], b_t = bhd[D + col], b_q = bhd[2 * D + col];
+        const float e_s = es[col], e_q = eq[col];
+        const float mf = skm[col], mb = skm[D + col];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = q * 4 + e;
+          const int d = dirr[e];
+          const float S = tanhf(acc[0 * NTH + t][e] + b_s) * e_s;
+          const float Tt = acc[1 * NTH + t][e] + b_t;
+          float Q = acc[2 * NTH + t][e] + b_q;
+          Q = (net.q_tanh ? tanhf(Q) : Q) * e_q;
+          const int idx = row * SX + col;
+          if (mode == 1) {
+            // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
+            const float g = gs[idx], v = vs[idx];
+            const float s = (d ? -0.5f : 0.5f) * eps * S;
+            const float kick = 0.5f * eps * (expf(eps * Q) * g - Tt);
+            vs[idx] = d ? expf(s) * (v + kick) : v * expf(s) - kick;
+            ld[e] += s;
+          } else {
+            // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd); keep mask per direction and sub-update
+            const float keep = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf);
+            const float x = xs[idx], v = vs[idx];
+            const float s = (d ? -eps : eps) * S;
+            const float drift = eps * (expf(eps * Q) * v + Tt);
+            const float upd = d ? expf(s) * (x - drift) : x * expf(s) + drift;
+            xs[idx] = keep * x + (1.f - keep) * upd;
+            ld[e] += (1.f - keep) * s;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = ld[e];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 1, 64);
+        if (r == 0) ldw[wave * kFM + q * 4 + e] += t;
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- leapfrog steps -----------------------------------------------------------
+  const float two_pi = 6.28318530717958647692f;
+  for (int step = p.step_begin; step < p.step_end; ++step) {
+    const int sf = step, sb = p.num_steps - 1 - step;       // gauge_dynamics.py:453-457
+    const float af = two_pi * (float)sf / (float)p.num_steps, ab = two_pi * (float)sb / (float)p.num_steps;
+    const float tcf = cosf(af), tsf = sinf(af), tcb = cosf(ab), tsb = sinf(ab);
+    float tcr[4], tsr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tcr[e] = dirr[e] ? tcb : tcf;
+      tsr[e] = dirr[e] ? tsb : tsf;
+    }
+    for (int i = tid; i < D; i += kFThreads) {
+      skm[i] = p.masks[(size_t)sf * D + i];
+      skm[D + i] = p.masks[(size_t)sb * D + i];
+    }
+    // (gs holds the force of the current x: from the prologue or the previous step's last kick)
+    __syncthreads();
+    net_update(p.vnet, cv, xs, 1, 0, tcr, tsr);               // momentum half-kick
+    for (int sub = 0; sub < 2; ++sub) {
+      // second input of XNet: keep (.) x   (gauge_dynamics.py:515-517)
+      for (int i = tid; i < kFM * D; i += kFThreads) {
+        const int rr = i / D, c = i - rr * D;
+        const int d = sdir[rr];
+        const float mf = skm[c], mb = skm[D + c];
+        const float keep = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf);
+        gs[rr * SX + c] = keep * xs[rr * SX + c];
+      }
+      __syncthreads();
+      net_update(p.xnet, cx, vs, 2, sub, tcr, tsr);           // position sub-update
+    }
+    (void)force_pass();                                        // force at the new position
+    net_update(p.vnet, cv, xs, 1, 0, tcr, tsr);               // second momentum half-kick
+  }
+
+  // ---- epilogue: energies, accept probability, write back -------------------------
+  const float act1 = force_pass();
+  const float kin1 = kinetic_pass();
+  if (fl == 0 && fc < nrow) {
+    const float sld = ((ldw[fc] + ldw[kFM + fc]) + ldw[2 * kFM + fc]) + ldw[3 * kFM + fc];
+    const int64_t rr = row0 + fc;
+    if (p.logdet) p.logdet[rr] = p.logdet_accumulate ? p.logdet[rr] + sld : sld;
+    if (p.p_accept) {
+      // gauge_dynamics.py:592-609; the O(100) Hamiltonians are differenced in fp64
+      const double dh = (double)p.beta * ((double)act0 - (double)act1) + ((double)kin0 - (double)kin1) +
+                        (double)sld;
+      const float pr = expf((float)fmin(dh, 0.0));
+      p.p_accept[rr] = isfinite(pr) ? pr : 0.f;
+    }
+  }
+  for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
+    const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
+    if (rr < nrow) {
+      *reinterpret_cast<f32x4*>(p.x_out + (row0 + rr) * D + c4) = *reinterpret_cast<const f32x4*>(xs + rr * SX + c4);
+      *reinterpret_cast<f32x4*>(p.v_out + (row0 + rr) * D + c4) = *reinterpret_cast<const f32x4*>(vs + rr * SX + c4);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int fused_net_supported(const l2hmc_dense_net* n) {
+  return n->D == 128 && n->H == 512 && n->Ka == 128 && n->Kb == 128;
+}
+
+int fused_plan_supported(const l2hmc_gauge_plan* p) {
+  return !p->hmc && fused_net_supported(&p->xnet) && fused_net_supported(&p->vnet) && p->xnet.packed &&
+         p->vnet.packed && 2 * p->T * p->X == 128;
+}
+
+int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
+                            const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
+                            float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
+                            hipStream_t stream) {
+  using Cfg = FusedCfg<128, 512>;
+  static bool attr_set = false;
+  const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
+      return L2HMC_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  FusedArgs a{};
+  a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = step_begin; a.step_end = step_end;
+  a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
+  a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
+  a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
+  const dim3 grid((unsigned)ceil_div(rows, kFM));
+  prof_before(kProfFused, stream);
+  hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512>), grid, dim3(kFThreads), lds, stream, a);
+  prof_after(kProfFused, stream);
+  L2HMC_CHECK_LAUNCH("gauge_traj_fused");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" size_t l2hmc_dense_pack_bytes(const l2hmc_dense_net* net) {
+  if (!net || !fused_net_supported(net)) return 0;
+  return sizeof(float) * ((size_t)(net->Ka + net->Kb) * net->H + (size_t)net->H * net->H + (size_t)3 * net->D * net->H);
+}
+
+extern "C" int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(net != nullptr && packed != nullptr, "dense_pack: NULL pointer");
+  L2HMC_REQUIRE(fused_net_supported(net), "dense_pack: shape (D=%d, H=%d, Ka=%d, Kb=%d) has no fused kernel",
+                net->D, net->H, net->Ka, net->Kb);
+  L2HMC_REQUIRE(net->w1_t && net->wh_t && net->whd_t, "dense_pack: NULL weight pointer");
+  hipLaunchKernelGGL(pack_fused_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *net, packed);
+  L2HMC_CHECK_LAUNCH("dense_pack");
+  return L2HMC_OK;
+}

@@ -178,6 +178,9 @@ struct GaugeWs {
   size_t bytes;
 };
 
+static bool use_fused(const l2hmc_gauge_plan* p) {
+  return !(p->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(p);
+}
 static int gauge_hmax(const l2hmc_gauge_plan* p) { return p->hmc ? 0 : hmax(p->xnet.H, p->vnet.H); }
 static int gauge_ncb(const l2hmc_gauge_plan* p) { return (int)ceil_div(2 * p->T * p->X, 32); }
 
@@ -332,6 +335,9 @@ static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, f
                               int64_t rows, float* sumlogdet, float* p_accept, const GaugeWs& w,
                               hipStream_t stream) {
   const int D = 2 * p->T * p->X;
+  if (use_fused(p))
+    return launch_fused_trajectory(p, beta, 0, p->num_steps, x, v, dir, rows, x, v, sumlogdet, 0, p_accept,
+                                   stream);
   if (int e = prepare_ws(p, rows, w, stream)) return e;
   if (p_accept) {
     if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, w.act0, nullptr, nullptr, nullptr, stream))
@@ -477,6 +483,8 @@ extern "C" int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, in
     return L2HMC_ERR_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (use_fused(plan))
+    return launch_fused_trajectory(plan, beta, step, step + 1, x, v, dir, rows, x, v, logdet, 1, nullptr, s);
   if (int e = prepare_ws(plan, rows, w, s)) return e;
   if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s)) return e;
   if (logdet) {

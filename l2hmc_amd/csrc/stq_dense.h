@@ -18,6 +18,7 @@ struct GemmReluArgs {
   float* out; int ldo;
   int64_t rows;
   int mtiles, ntiles;
+  unsigned long long* stamps;          // diagnostic builds only (-DL2HMC_STAMPS), else NULL
 };
 
 // heads: (S,T,Q) = h2 . Whd^T + bhd, then materialise or fused v/x update
@@ -38,11 +39,44 @@ struct HeadsArgs {
   float eps;
   float* ld_part; int ncb;               // [rows][ncb] log-det partials, += own slot
   int mtiles, ntiles;
+  unsigned long long* stamps;            // diagnostic builds only
 };
+
+// In-kernel cycle stamps (cdna_hip_programming.md section 7): compiled in only with
+// -DL2HMC_STAMPS, never in the shipped library.  Slot layout per workgroup: 8 words.
+#ifdef L2HMC_STAMPS
+extern unsigned long long* g_stamp_buf;
+#define L2HMC_STAMP(i)                                                                    \
+  do {                                                                                    \
+    if (p.stamps && threadIdx.x == 0) {                                                   \
+      unsigned long long t_;                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      p.stamps[blockIdx.x * 8 + (i)] = t_;                                                \
+    }                                                                                     \
+  } while (0)
+#define L2HMC_STAMP_REAL(i)                                                               \
+  do {                                                                                    \
+    if (p.stamps && threadIdx.x == 0) {                                                   \
+      unsigned long long t_;                                                              \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      p.stamps[blockIdx.x * 8 + (i)] = t_;                                                \
+    }                                                                                     \
+  } while (0)
+#else
+#define L2HMC_STAMP(i) do {} while (0)
+#define L2HMC_STAMP_REAL(i) do {} while (0)
+#endif
 
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
 int launch_heads(HeadsArgs& a, hipStream_t stream);
 int dense_net_supported(const l2hmc_dense_net* n);
+int fused_plan_supported(const l2hmc_gauge_plan* p);
+int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
+                            const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
+                            float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
+                            hipStream_t stream);
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream);
 

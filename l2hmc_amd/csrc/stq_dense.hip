@@ -46,7 +46,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // =====================================================================
 
 
-template <int BM>
+// KIND 1: first layer (two k-contiguous sources, optional column mask, time term)
+// KIND 2: hidden layer (single source, plain bias)
+template <int BM, int KIND>
 __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int BN = 128;
   constexpr int LDK = BK + 4;              // 36 floats = 144 B rows: conflict-free b128 reads
@@ -57,6 +59,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
   constexpr int STAGE = (BM + BN) * LDK;   // one A|B buffer pair
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
+  L2HMC_STAMP_REAL(4);
+  L2HMC_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     a_row[i] = c >> 3;
     a_kc[i] = (c & 7) * 4;
     a_ok[i] = (m0 + a_row[i]) < p.rows;
-    a_dir[i] = (p.dir && a_ok[i]) ? p.dir[m0 + a_row[i]] : 0;
+    a_dir[i] = (KIND == 1 && p.dir && a_ok[i]) ? p.dir[m0 + a_row[i]] : 0;
   }
   int b_row[B_CH], b_kc[B_CH];
   bool b_ok[B_CH];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     for (int i = 0; i < A_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (a_ok[i]) {
-        if (k0 < p.K1) {
+        if (KIND == 2 || k0 < p.K1) {
           v = *reinterpret_cast<const f32x4*>(p.A1 + (m0 + a_row[i]) * p.lda1 + k0 + a_kc[i]);
         } else {
           const int kk = k0 - p.K1 + a_kc[i];
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  L2HMC_STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     __syncthreads();
   }
 
+  L2HMC_STAMP(2);
   // --- epilogue: + bias (+ t.Wt), relu, store.  C layout of 32x32 MFMA:
   // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma unroll
@@ -170,24 +176,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     const int col = n0 + wn * 64 + j * 32 + r;
     const bool cok = col < p.N;
     const float bj = cok ? p.bias[col] : 0.f;
-    const float w0 = (cok && p.wt0) ? p.wt0[col] : 0.f;
-    const float w1 = (cok && p.wt0) ? p.wt1[col] : 0.f;
+    const float w0 = (KIND == 1 && cok && p.wt0) ? p.wt0[col] : 0.f;
+    const float w1 = (KIND == 1 && cok && p.wt0) ? p.wt1[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (row < p.rows && cok) {
-          const int d = p.dir ? p.dir[row] : 0;
-          const float tc = d ? p.tc_b : p.tc_f;
-          const float ts = d ? p.ts_b : p.ts_f;
           float h = acc[i][j][e] + bj;
-          h += tc * w0 + ts * w1;
+          if (KIND == 1) {
+            const int d = p.dir ? p.dir[row] : 0;
+            const float tc = d ? p.tc_b : p.tc_f;
+            const float ts = d ? p.ts_b : p.ts_f;
+            h += tc * w0 + ts * w1;
+          }
           p.out[row * p.ldo + col] = fmaxf(h, 0.f);
         }
       }
     }
   }
+  L2HMC_STAMP(3);
+  L2HMC_STAMP_REAL(5);
 }
 
 // =====================================================================
@@ -205,6 +215,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   constexpr int STAGE = (BM + NB) * LDK;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
+  L2HMC_STAMP_REAL(4);
+  L2HMC_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  L2HMC_STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     __syncthreads();
   }
 
+  L2HMC_STAMP(2);
   // --- epilogue.  C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
   float ld[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -366,11 +380,22 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
       if (r == 0 && row < p.rows) p.ld_part[row * p.ncb + nt_id] += t;
     }
   }
+  L2HMC_STAMP(3);
+  L2HMC_STAMP_REAL(5);
 }
 
 // ---------------------------------------------------------------------
 // host-side launchers (used by the C ABI in capi.hip)
 // ---------------------------------------------------------------------
+#ifdef L2HMC_STAMPS
+unsigned long long* g_stamp_buf = nullptr;
+int g_stamp_cls = 0;
+extern "C" void l2hmc_debug_set_stamps(unsigned long long* buf, int cls) {
+  g_stamp_buf = buf;
+  g_stamp_cls = cls;
+}
+#endif
+
 static int check_ptr16(const void* p, const char* what) {
   L2HMC_REQUIRE(p != nullptr, "%s is NULL", what);
   L2HMC_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "%s is not 16-byte aligned", what);
@@ -394,16 +419,27 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     if (int e = check_ptr16(a.cmask_f, "gemm mask")) return e;
     if (int e = check_ptr16(a.cmask_b, "gemm mask (bwd)")) return e;
   }
+#ifdef L2HMC_STAMPS
+  a.stamps = (g_stamp_cls == ((a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr) ? 1 : 2)) ? g_stamp_buf : nullptr;
+#endif
   a.ntiles = (int)ceil_div(a.N, 128);
   // 128-row tiles once they still fill the chip (>= 2 tiles per CU), else 64-row tiles
   const int64_t t128 = ceil_div(a.rows, 128) * a.ntiles;
+  const bool first = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr;
+  const int cls = first ? kProfGemmL1 : kProfGemmL2;
+  prof_before(cls, stream);
   if (t128 >= 512) {
     a.mtiles = (int)ceil_div(a.rows, 128);
-    hipLaunchKernelGGL(gemm_relu_kernel<128>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+    const dim3 grid(a.mtiles * a.ntiles);
+    if (first) hipLaunchKernelGGL((gemm_relu_kernel<128, 1>), grid, dim3(kGemmThreads), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_relu_kernel<128, 2>), grid, dim3(kGemmThreads), 0, stream, a);
   } else {
     a.mtiles = (int)ceil_div(a.rows, 64);
-    hipLaunchKernelGGL(gemm_relu_kernel<64>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+    const dim3 grid(a.mtiles * a.ntiles);
+    if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1>), grid, dim3(kGemmThreads), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_relu_kernel<64, 2>), grid, dim3(kGemmThreads), 0, stream, a);
   }
+  prof_after(cls, stream);
   L2HMC_CHECK_LAUNCH("gemm_relu");
   return L2HMC_OK;
 }
@@ -412,10 +448,15 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.K % BK == 0 && a.lda % 4 == 0, "heads: K=%d must be a multiple of %d", a.K, BK);
   if (int e = check_ptr16(a.A, "heads A")) return e;
   if (int e = check_ptr16(a.Wt, "heads W")) return e;
+#ifdef L2HMC_STAMPS
+  a.stamps = g_stamp_cls == 3 ? g_stamp_buf : nullptr;
+#endif
   a.mtiles = (int)ceil_div(a.rows, 64);
   a.ntiles = (int)ceil_div(a.D, 32);
   L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
+  prof_before(kProfHeads, stream);
   hipLaunchKernelGGL(heads_kernel, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  prof_after(kProfHeads, stream);
   L2HMC_CHECK_LAUNCH("heads");
   return L2HMC_OK;
 }

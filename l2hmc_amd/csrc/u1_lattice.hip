@@ -167,8 +167,10 @@ int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float bet
   const size_t lds = sizeof(float) * ((size_t)cpw * 3 * sites + 3 * kLatThreads);
   L2HMC_REQUIRE(lds <= 160 * 1024, "u1_action_force: lattice %dx%d does not fit LDS", T, X);
   const int64_t grid = ceil_div(rows, cpw);
+  prof_before(kProfU1, stream);
   hipLaunchKernelGGL(u1_action_force_kernel, dim3((unsigned)grid), dim3(kLatThreads), lds, stream, x,
                      rows, T, X, beta, cpw, action, force, avg_plaq, top_charge);
+  prof_after(kProfU1, stream);
   L2HMC_CHECK_LAUNCH("u1_action_force");
   return L2HMC_OK;
 }

@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing for the sampler: chains are independent, so each rank
+owns a contiguous block of chains and a replica of the weights / masks; the
+only exchange is one fused all-reduce of per-step scalar sums (the reduce_mean
+of gauge_model.py:795 across shards).  `torch.distributed` with backend "nccl"
+is RCCL over xGMI on ROCm; the same code runs on "gloo" for CPU tests."""
+import torch
+
+
+def shard_bounds(num_chains, world_size, rank):
+    """Contiguous block [lo, hi) of chains owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(int(num_chains), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_state(tensors, dist, src=0):
+    """Replicate weights / masks / eps from `src` (what hvd.BroadcastGlobalVariablesHook(0)
+    does in gauge_model.py:1008)."""
+    if dist is None or not dist.is_initialized():
+        return
+    for t in tensors:
+        dist.broadcast(t, src=src)
+
+
+class StepStats:
+    """Per-step fused scalar buffer [sum p_accept, sum |dQ|, n_chains]; one
+    asynchronous all-reduce(SUM) per MCMC step on a side stream so the next
+    trajectory does not wait for it."""
+
+    def __init__(self, device, dist=None):
+        self.device = torch.device(device)
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.total = torch.zeros(3, dtype=torch.float64)
+        self._pending = []
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def push(self, p_accept, abs_dq):
+        buf = torch.stack([p_accept.sum(dtype=torch.float32), abs_dq.sum(dtype=torch.float32),
+                           torch.tensor(float(p_accept.numel()), dtype=torch.float32, device=p_accept.device)])
+        work = None
+        if self.dist is not None:
+            if self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side):
+                    work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+                buf.record_stream(self._side)
+            else:
+                work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((buf, work))
+        if len(self._pending) > 64:
+            self._drain(keep=8)
+
+    def _drain(self, keep=0):
+        while len(self._pending) > keep:
+            buf, work = self._pending.pop(0)
+            if work is not None:
+                work.wait()
+            self.total += buf.detach().to("cpu", torch.float64)
+
+    def wait(self):
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._drain(0)
+
+    def mean_accept(self):
+        self.wait()
+        return float(self.total[0] / self.total[2]) if self.total[2] > 0 else float("nan")
+
+    def mean_abs_dq(self):
+        self.wait()
+        return float(self.total[1] / self.total[2]) if self.total[2] > 0 else float("nan")

@@ -32,6 +32,7 @@ class GaugeDynamics:
         self.hmc, self.network_arch, self.num_steps = False, 'generic', 5
         self.eps_trainable, self.data_format = True, 'channels_last'
         self.both_directions = True      # integrate fwd AND bwd like :211-218; False = selected only
+        self.fused = True                # whole-trajectory kernel where the shape has one
         for key, val in kwargs.items():
             if key != 'eps':             # :73-75
                 setattr(self, key, val)
@@ -106,7 +107,8 @@ class GaugeDynamics:
     # ---- plumbing ----------------------------------------------------------
     def _plan(self):
         p = _lib.GaugePlan(T=self.lattice.time_size, X=self.lattice.space_size, num_steps=self.num_steps,
-                           hmc=int(bool(self.hmc)), eps=float(self.eps), reserved=0.,
+                           hmc=int(bool(self.hmc)), eps=float(self.eps),
+                           flags=0 if self.fused else _lib.PLAN_LAYERED,
                            masks=_lib.dev_ptr(self.mask, name="mask"))
         if not self.hmc:
             p.xnet = self.position_fn.pack()

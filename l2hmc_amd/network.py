@@ -108,8 +108,14 @@ class _DenseSTQ:
                 whd_t=torch.stack([ls.kernel.t(), ltr.kernel.t(), lq.kernel.t()]).contiguous(),  # [3][D][H]
                 bhd=torch.stack([ls.bias, ltr.bias, lq.bias]).contiguous(),               # [3][D]
                 coeff_s=cs.reshape(-1).contiguous(), coeff_q=cq.reshape(-1).contiguous())
-            st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0,
+            st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0, packed=None,
                                **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
+            L = _lib.lib()
+            nbytes = L.l2hmc_dense_pack_bytes(C.byref(st))
+            if nbytes:      # fragment-ordered image for the fused whole-trajectory kernel
+                bufs["packed"] = torch.empty(nbytes // 4, dtype=torch.float32, device=self._device)
+                _lib.check(L.l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr()))
+                st.packed = bufs["packed"].data_ptr()
             self._packed = (st, bufs)
         return self._packed[0]
 

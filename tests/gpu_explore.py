@@ -47,13 +47,18 @@ def main():
               flush=True)
 
     # ---- leapfrog / trajectory / transition, cfg-3 shape
-    for regime in ("init", "stress"):
-        for (T, X, N, eps, beta, B) in [(8, 8, 10, 0.25, 2.0, 64), (4, 4, 3, 0.2, 2.5, 10)]:
+    for regime, fused in (("init", True), ("init", False), ("mild", True), ("mild", False), ("stress", True)):
+        for (T, X, N, eps, beta, B) in [(8, 8, 10, 0.25, 2.0, 71), (4, 4, 3, 0.2, 2.5, 10)]:
+            if regime == "stress" and T == 8:
+                N = 3
             D = 2 * T * X
             xp, vp = H.gauge_weights(T, X, regime=regime)
             orc = H.gauge_oracle(T, X, N, eps, xp, vp)
             orc32 = H.gauge_oracle(T, X, N, eps, xp, vp, dtype=np.float32)
             dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+            dyn.fused = fused
+            regime_ = regime
+            regime = f"{regime_} fused={fused}"
             x, v0f, v0b, coin, u = H.gauge_inputs(B, D)
             x1, v1, ld = dyn._forward_lf(x, v0f, beta, 1)
             ox, ov, old = orc._forward_lf(x, v0f, beta, 1)
@@ -78,6 +83,7 @@ def main():
                 print(f"[{regime} {T}x{X}] transition both={both}: " +
                       " ".join(f"{n} {H.relerr(np_(g), w):.2e}" for n, g, w in zip(("xp", "vp", "p", "xo"), got, want)),
                       flush=True)
+            regime = regime_
 
     # ---- MoG / SCG
     for name, tgt_o, nh, N in (("mog", H.mog_target_oracle(), 50, 10), ("scg", H.scg_target_oracle(), 10, 5)):
@@ -110,8 +116,9 @@ def main():
     N, eps, beta, B = 10, 0.25, 2.0, 2048
     xp, vp = H.gauge_weights(T, X, regime="init")
     orc = H.gauge_oracle(T, X, N, eps, xp, vp)
-    for both in (True, False):
+    for both, fused in ((True, True), (False, True), (True, False)):
         dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B, both_directions=both)
+        dyn.fused = fused
         x = torch.rand(B, 128, device="cuda") * 6.28
         for _ in range(3):
             out = dyn(x, beta)
@@ -123,7 +130,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
         flops = (2 if both else 1) * B * N * 4726784
-        print(f"cfg3 both={both}: {dt*1e3:.3f} ms/transition, useful {B*N/dt/1e6:.2f} M chain-LF/s, "
+        print(f"cfg3 both={both} fused={fused}: {dt*1e3:.3f} ms/transition, useful {B*N/dt/1e6:.2f} M chain-LF/s, "
               f"{flops/dt/1e12:.1f} TFLOP/s, mean p {out[2].mean().item():.3f}", flush=True)
 
 

@@ -11,6 +11,8 @@ REGIMES = {
     "init": dict(head_factor=0.001, bias_std=0.0, coeff_std=0.0),
     # SURVEY.md 8d "stress": eps*S, eps*Q reach O(0.3) so exp / tanh / log-det paths matter
     "stress": dict(head_factor=0.1, bias_std=0.05, coeff_std=0.2),
+    # same paths exercised, gentle enough to stay finite over 10+ leapfrog steps at D=128
+    "mild": dict(head_factor=0.01, bias_std=0.02, coeff_std=0.1),
 }
 
 
