@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--selected-only", action="store_true",
                     help="integrate only the direction each chain's coin selects (not the reference's work)")
+    ap.add_argument("--layered", action="store_true", help="use the layer-by-layer kernels (no fused trajectory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -79,6 +80,7 @@ def main():
     both = not args.selected_only
     dyn, xp, vp, masks = build_dynamics(BATCH, both)
     dyn._seed = 1000 + rank                       # independent chains per rank
+    dyn.fused = not args.layered
     D = 2 * L * L
     x = torch.empty(BATCH, D, device=dev)
     _lib.check(_lib.lib().l2hmc_fill_uniform(x.data_ptr(), x.numel(), 103 + rank, 0, _lib.stream_ptr()))
@@ -136,7 +138,10 @@ def main():
         rows = (2 if both else 1) * BATCH
         Hd = HID_MULT * D
         per_class = {}
-        for cls, name, flops in ((1, "gemm_relu_kernel<64,1> (first layer)", 2.0 * rows * Hd * 2 * D),
+        # algorithmic FLOPs per launch: SURVEY.md 8 sizes table (8 x net MACs per chain-LF step)
+        for cls, name, flops in ((5, "gauge_traj_fused_kernel<128,512> (whole trajectory)",
+                                  8.0 * net_macs(D, Hd) * rows * N_LF),
+                                 (1, "gemm_relu_kernel<64,1> (first layer)", 2.0 * rows * Hd * 2 * D),
                                  (2, "gemm_relu_kernel<64,2> (hidden layer)", 2.0 * rows * Hd * Hd),
                                  (3, "heads_kernel (S/T/Q + update)", 2.0 * rows * 3 * D * Hd)):
             _lib.check(Lh.l2hmc_profile_begin(cls))
@@ -148,6 +153,7 @@ def main():
             per_class[cls] = dict(kernel=name, launches=n.value, avg_us=1e3 * ms.value / max(n.value, 1),
                                   flops_per_launch=flops,
                                   tflops=flops / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0)
+        per_class = {k: v for k, v in per_class.items() if v["launches"]}
         dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
         out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,

@@ -48,4 +48,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// exp(min(dh, 0)) with the reference's NaN semantics: tf.minimum propagates NaN and
+// gauge_dynamics.py:609 / utils/dynamics.py:319 then map every non-finite result to 0.
+template <typename T>
+__device__ __forceinline__ float accept_from_delta(T dh) {
+  if (dh != dh) return 0.f;
+  const float pr = expf((float)(dh < (T)0 ? dh : (T)0));
+  return isfinite(pr) ? pr : 0.f;
+}
+
 }  // namespace l2hmc

@@ -400,8 +400,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       // gauge_dynamics.py:592-609; the O(100) Hamiltonians are differenced in fp64
       const double dh = (double)p.beta * ((double)act0 - (double)act1) + ((double)kin0 - (double)kin1) +
                         (double)sld;
-      const float pr = expf((float)fmin(dh, 0.0));
-      p.p_accept[rr] = isfinite(pr) ? pr : 0.f;
+      p.p_accept[rr] = accept_from_delta(dh);
     }
   }
   for (int i = tid; i < kFM * (D / 4); i += kFThreads) {

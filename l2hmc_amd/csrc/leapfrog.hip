@@ -81,9 +81,7 @@ __global__ void accept_prob_kernel(const float* __restrict__ h_old, const float*
                                    const float* __restrict__ sld, int64_t n, float* __restrict__ p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float e = fminf(h_old[i] - h_new[i] + sld[i], 0.f);
-  const float pr = expf(e);
-  p[i] = isfinite(pr) ? pr : 0.f;
+  p[i] = accept_from_delta(h_old[i] - h_new[i] + sld[i]);
 }
 
 // Same from the pieces the trajectory has at hand.  The difference of the two
@@ -102,8 +100,7 @@ __global__ void accept_from_parts_kernel(const float* __restrict__ act0, const f
   if (p) {
     const double dh = (double)beta * ((double)act0[i] - (double)act1[i]) +
                       ((double)kin0[i] - (double)kin1[i]) + (double)s;
-    const float pr = expf((float)fmin(dh, 0.0));
-    p[i] = isfinite(pr) ? pr : 0.f;
+    p[i] = accept_from_delta(dh);
   }
 }
 

@@ -295,8 +295,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
   }
   if (a.sumlogdet) a.sumlogdet[r] = logdet;
   if (a.p_accept) {
-    const float pr = expf(fminf(H0 - H1 + logdet, 0.f));   // utils/dynamics.py:312-319
-    a.p_accept[r] = isfinite(pr) ? pr : 0.f;
+    a.p_accept[r] = accept_from_delta(H0 - H1 + logdet);   // utils/dynamics.py:312-319
   }
 }
 

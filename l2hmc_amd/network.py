@@ -93,21 +93,26 @@ class _DenseSTQ:
             self.load_state({k: f[k] for k in f.files})
 
     # ---- packing for the HIP kernels
+    def _pack_tensors(self):
+        """Reference-layout weights -> the k-contiguous buffers of struct l2hmc_dense_net."""
+        la, lb, lt, lh, ls, ltr, lq = self._layers()
+        cs, cq = (getattr(self, n) for n in self._coeff_names)
+        return dict(
+            w1_t=torch.cat([la.kernel, lb.kernel], dim=0).t().contiguous(),         # [H][Ka+Kb]
+            wt=lt.kernel.contiguous(),                                               # [2][H]
+            b1=(la.bias + lb.bias + lt.bias).contiguous(),
+            wh_t=lh.kernel.t().contiguous(),                                          # [H][H] (out, in)
+            bh=lh.bias.contiguous(),
+            whd_t=torch.stack([ls.kernel.t(), ltr.kernel.t(), lq.kernel.t()]).contiguous(),  # [3][D][H]
+            bhd=torch.stack([ls.bias, ltr.bias, lq.bias]).contiguous(),               # [3][D]
+            coeff_s=cs.reshape(-1).contiguous(), coeff_q=cq.reshape(-1).contiguous())
+
     def pack(self):
-        """(struct l2hmc_dense_net, keep-alive tensors); rebuilt after load_state()."""
+        """struct l2hmc_dense_net over device buffers (kept alive here); rebuilt after load_state()."""
         if self._packed is None:
             la, lb, lt, lh, ls, ltr, lq = self._layers()
-            cs, cq = (getattr(self, n) for n in self._coeff_names)
             Ka, Kb, H, D = la.kernel.shape[0], lb.kernel.shape[0], lh.kernel.shape[0], ls.kernel.shape[1]
-            bufs = dict(
-                w1_t=torch.cat([la.kernel, lb.kernel], dim=0).t().contiguous(),         # [H][Ka+Kb]
-                wt=lt.kernel.contiguous(),                                               # [2][H]
-                b1=(la.bias + lb.bias + lt.bias).contiguous(),
-                wh_t=lh.kernel.t().contiguous(),                                          # [H][H] (out, in)
-                bh=lh.bias.contiguous(),
-                whd_t=torch.stack([ls.kernel.t(), ltr.kernel.t(), lq.kernel.t()]).contiguous(),  # [3][D][H]
-                bhd=torch.stack([ls.bias, ltr.bias, lq.bias]).contiguous(),               # [3][D]
-                coeff_s=cs.reshape(-1).contiguous(), coeff_q=cq.reshape(-1).contiguous())
+            bufs = self._pack_tensors()
             st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0, packed=None,
                                **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
             L = _lib.lib()

@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950,
+loads, exports every symbol include/l2hmc_hip.h declares, and rejects bad
+arguments on the host (no kernel is launched in this file)."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from l2hmc_amd import _lib, build as lbuild
+
+
+@pytest.fixture(scope="module")
+def L():
+    lbuild.build()            # hipcc cross-compiles without a GPU; building is not a fallback
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/l2hmc_hip.h but not exported"
+    assert set(_lib._PROTOS) == set(declared), "ctypes prototypes out of sync with the header"
+    assert L.l2hmc_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+    # pointers are 8 bytes; a mismatch here would silently corrupt every call
+    assert C.sizeof(_lib.DenseNet) == 4 * 4 + 9 * 8 + 2 * 4 + 8
+    assert C.sizeof(_lib.GaugePlan) == 6 * 4 + 8 + 2 * C.sizeof(_lib.DenseNet)
+    assert C.sizeof(_lib.MogTarget) == 4 * 4 + 3 * 8
+
+
+def test_empty_inputs_are_ok_without_a_gpu(L):
+    assert L.l2hmc_u1_action_force(None, 0, 8, 8, 1.0, None, None, None, None, None) == 0
+    assert L.l2hmc_kinetic_energy(None, 0, 128, None, None) == 0
+    assert L.l2hmc_fill_normal(None, 0, 1, 0, None) == 0
+    assert L.l2hmc_accept_prob(None, None, None, 0, None, None) == 0
+
+
+def test_bad_arguments_are_rejected_on_the_host(L):
+    assert L.l2hmc_u1_action_force(None, 4, 8, 8, 1.0, None, None, None, None, None) == 1
+    assert b"NULL" in L.l2hmc_last_error()
+    assert L.l2hmc_u1_action_force(None, -1, 8, 8, 1.0, None, None, None, None, None) == 1
+    assert L.l2hmc_lf_update_v(None, None, None, None, None, 0.1, 2, 4, 128, None, None, None) == 1
+    with pytest.raises(ValueError):
+        _lib.check(L.l2hmc_kinetic_energy(None, 3, 0, None, None))
+    # a net whose widths the MFMA path cannot tile is refused, not silently mis-computed
+    net = _lib.DenseNet(D=2, H=50, Ka=2, Kb=2)
+    assert L.l2hmc_stq_dense(C.byref(net), None, None, None, 1.0, 0.0, 4, None, None, None, None, 0, None) == 1
+    assert b"multiples of 32" in L.l2hmc_last_error()
+    assert L.l2hmc_dense_pack_bytes(C.byref(net)) == 0
+    plan = _lib.GaugePlan(T=8, X=8, num_steps=0, hmc=1)
+    assert L.l2hmc_gauge_trajectory(C.byref(plan), 1.0, None, None, None, 4, None, None, None, None, None, 0,
+                                    None) == 1
+
+
+def test_workspace_queries(L):
+    net = _lib.DenseNet(D=128, H=512, Ka=128, Kb=128)
+    assert L.l2hmc_dense_pack_bytes(C.byref(net)) == 4 * (256 * 512 + 512 * 512 + 384 * 512)
+    plan = _lib.GaugePlan(T=8, X=8, num_steps=10, hmc=0, xnet=net, vnet=net)
+    one = L.l2hmc_gauge_ws_bytes(C.byref(plan), 4096)
+    assert one >= 2 * 4096 * 512 * 4 + 4096 * 128 * 4
+    both = L.l2hmc_gauge_transition_ws_bytes(C.byref(plan), 2048, 1)
+    assert both >= one + 2 * 4096 * 128 * 4
+    assert L.l2hmc_stq_ws_bytes(100, 512) >= 2 * 100 * 512 * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Host classes refuse CPU tensors instead of computing on the CPU."""
+    if torch.cuda.is_available():
+        pytest.skip("checked on the GPU-less builder")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.dev_ptr(torch.zeros(4), name="x")
+    from l2hmc_amd.network import GenericNet
+    net = GenericNet(model_name='XNet', device=torch.device("cpu"), x_dim=128, num_hidden=512, factor=2.,
+                     name_scope='position', links_shape=(8, 8, 2))
+    with pytest.raises(RuntimeError):
+        net([torch.zeros(4, 128), torch.zeros(4, 128), torch.tensor([[1., 0.]])])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(tmp_path, "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,457 @@
+"""GPU parity tests: every call goes through the C ABI of libl2hmc_hip.so and is
+compared with the CPU oracle on identical injected inputs.
+
+Tolerances.  north_star: "within 1e-5 relative fp32".  `relerr` is the max
+abs deviation relative to the tensor's own scale (>= 1).
+  * single ops and single leapfrog steps:           TOL_OP  = 1e-5 (measured ~2e-7..2e-6)
+  * accept probabilities (O(1), exp of an O(100) energy difference in fp32):  TOL_P = 2e-5 abs
+  * whole trajectories: a hot-start trajectory at eps=0.25 amplifies rounding
+    ~100x over 10 steps (single steps agree to ~2e-7, the fp32 floor), so even
+    the reference's own fp32 graph is ~1e-5 away from exact arithmetic at the
+    end: the fp32 NumPy oracle (same op order as the reference) measures that
+    intrinsic deviation on the same inputs.  The HIP result must be
+    indistinguishable from such an fp32 evaluation: max error <= max(TOL_OP,
+    6 x intrinsic max) and RMS error <= max(TOL_OP / 3, 2.5 x intrinsic RMS)
+    against the fp64 oracle (the max over ~10^4 chaotically amplified elements
+    is heavy-tailed, hence two norms).  On benign dynamics (small step, near-cold
+    start) the whole trajectory is held to TOL_OP outright
+    (test_trajectory_within_1e5_on_benign_dynamics).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice as olat, nets as onets, dynamics as ogen
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-5
+TOL_P = 2e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def np_(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def rmserr(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.sqrt(np.mean((got - want) ** 2)) / max(1.0, np.max(np.abs(want))))
+
+
+def assert_fp32_equivalent(got, want64, want32, what):
+    """`got` is as close to the fp64 oracle as an fp32 evaluation in the reference's op order."""
+    emax, imax = H.relerr(got, want64), H.relerr(want32, want64)
+    erms, irms = rmserr(got, want64), rmserr(want32, want64)
+    assert emax < max(TOL_OP, 6 * imax), f"{what}: max err {emax:.2e} vs intrinsic fp32 {imax:.2e}"
+    assert erms < max(TOL_OP / 3, 2.5 * irms), f"{what}: rms err {erms:.2e} vs intrinsic fp32 {irms:.2e}"
+
+
+@pytest.fixture(scope="module")
+def la():
+    import l2hmc_amd
+    from l2hmc_amd import _lib
+    _lib.lib()
+    return l2hmc_amd
+
+
+def test_native_library_is_the_one_loaded(la):
+    maps = open("/proc/self/maps").read()
+    assert "l2hmc_amd/libl2hmc_hip.so" in maps
+
+
+# ----------------------------------------------------------------- lattice
+@pytest.mark.parametrize("T,X,B", [(8, 8, 7), (8, 8, 1), (16, 16, 5), (32, 32, 3), (4, 6, 9), (17, 17, 2), (4, 4, 300)])
+def test_u1_action_force_observables(la, T, X, B):
+    x = np.random.default_rng(1).uniform(-7, 7, (B, 2 * T * X)).astype(np.float32)
+    o = la.u1_observables(x, T, X, beta=2.5, want_force=True)
+    x64 = x.astype(np.float64)
+    assert H.relerr(np_(o["action"]), olat.total_action(x64, T, X)) < TOL_OP
+    assert H.relerr(np_(o["force"]), 2.5 * olat.grad_action(x64, T, X)) < TOL_OP
+    assert H.relerr(np_(o["avg_plaq"]), olat.avg_plaq(x64, T, X)) < TOL_OP
+    assert H.relerr(np_(o["top_charge"]), olat.top_charge(x64, T, X)) < TOL_OP
+    lat = la.GaugeLattice(T, X, 2, 'U1', num_samples=B, rand=False)
+    assert H.relerr(np_(lat.calc_plaq_sums(x)), olat.plaq_sums(x64, T, X)) < TOL_OP
+
+
+def test_u1_known_answers_and_edge_cases(la):
+    lat = la.GaugeLattice(8, 8, 2, 'U1', num_samples=5, rand=False)
+    S, plaq, Q = lat.calc_plaq_observables(lat.samples.reshape(5, -1))      # cold start: notebook step-0 row
+    assert torch.all(S == 0) and torch.all(plaq == 1) and torch.all(Q == 0)
+    assert torch.all(lat.grad_action(lat.samples.reshape(5, -1), 2.0) == 0)
+    # pure gauge transformation leaves every plaquette invariant
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0, 2 * np.pi, (3, 8, 8, 2))
+    lam = rng.uniform(0, 2 * np.pi, (3, 8, 8))
+    xg = x.copy()
+    xg[..., 0] += lam - np.roll(lam, -1, axis=1)      # link 0 runs along i (x1[i+1,j] closes the plaquette)
+    xg[..., 1] += lam - np.roll(lam, -1, axis=2)      # link 1 runs along j
+    a = la.u1_observables(x.reshape(3, -1), 8, 8)["action"]
+    b = la.u1_observables(xg.reshape(3, -1), 8, 8)["action"]
+    assert H.relerr(np_(b), np_(a)) < 1e-5
+    # empty batch
+    e = la.u1_observables(np.zeros((0, 128), np.float32), 8, 8, want_force=True)
+    assert e["action"].shape == (0,) and e["force"].shape == (0, 128)
+    with pytest.raises(NotImplementedError):
+        la.GaugeLattice(8, 8, 2, 'SU2', num_samples=2)
+
+
+def test_golden_u1(la):
+    g = np.load(os.path.join(GOLD, "u1_obs.npz"))
+    for (T, X) in ((8, 8), (4, 6)):
+        k = f"{T}x{X}"
+        o = la.u1_observables(g[k + "/x"], T, X, beta=2.5, want_force=True)
+        assert H.relerr(np_(o["action"]), g[k + "/action"]) < TOL_OP
+        assert H.relerr(np_(o["force"]), g[k + "/force_beta2.5"]) < TOL_OP
+        assert H.relerr(np_(o["top_charge"]), g[k + "/top_charge"]) < TOL_OP
+
+
+# ----------------------------------------------------------------- dense S/T/Q net
+@pytest.mark.parametrize("regime", ["init", "stress"])
+@pytest.mark.parametrize("D,rows", [(128, 100), (128, 1), (32, 65), (512, 70)])
+def test_stq_dense_matches_generic_net(la, regime, D, rows):
+    rng = np.random.default_rng(5)
+    p = onets.init_generic_net(np.random.default_rng(106), D, 4 * D, 2., **H.REGIMES[regime])
+    net = la.GenericNet(model_name='XNet', x_dim=D, num_hidden=4 * D, factor=2., name_scope='position',
+                        links_shape=(1, D // 2, 2))
+    net.load_state(p)
+    a, b = rng.standard_normal((rows, D)), rng.uniform(0, 6.3, (rows, D))
+    t = np.array([[np.cos(0.7), np.sin(0.7)]])
+    S, T, Q = net([a, b, t])
+    # the oracle gets the fp32-rounded inputs the kernel sees
+    a32, b32 = a.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    p32 = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    So, To, Qo = onets.generic_net(p32, [a32, b32, np.tile(t.astype(np.float32).astype(np.float64), (rows, 1))])
+    assert H.relerr(np_(S), So) < TOL_OP and H.relerr(np_(T), To) < TOL_OP and H.relerr(np_(Q), Qo) < TOL_OP
+    assert np.abs(So).max() > (0.1 if regime == "stress" else 1e-3)      # the outputs are not trivially zero
+
+
+def test_stq_dense_rejects_untileable_widths(la):
+    net = la.GenericNet(model_name='XNet', x_dim=24, num_hidden=96, factor=2., name_scope='p', links_shape=(3, 4, 2))
+    with pytest.raises(ValueError, match="multiples of 32"):
+        net([np.zeros((4, 24)), np.zeros((4, 24)), np.array([[1., 0.]])])
+
+
+# ----------------------------------------------------------------- gauge dynamics
+def _pair(T, X, N, eps, B, regime, fused=True, hmc=False, both=True):
+    xp, vp = H.gauge_weights(T, X, regime=regime)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp, hmc=hmc)
+    orc32 = H.gauge_oracle(T, X, N, eps, xp, vp, hmc=hmc, dtype=np.float32)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B, hmc=hmc, both_directions=both)
+    dyn.fused = fused
+    return orc, orc32, dyn
+
+
+CASES = [  # T, X, N, eps, beta, B, regime, fused
+    (8, 8, 10, 0.25, 2.0, 71, "init", True),      # cfg-3 shape, whole-trajectory kernel, ragged batch
+    (8, 8, 10, 0.25, 2.0, 71, "init", False),     # same through the layer-by-layer kernels
+    (8, 8, 10, 0.25, 2.0, 33, "mild", True),
+    (8, 8, 3, 0.2, 2.5, 16, "stress", True),
+    (8, 8, 3, 0.2, 2.5, 17, "stress", False),
+    (4, 4, 3, 0.2, 2.5, 10, "stress", True),      # D=32: no fused kernel for this shape -> layered path
+    (16, 16, 2, 0.1, 3.0, 5, "init", True),       # D=512, H=2048
+]
+
+
+@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES)
+def test_leapfrog_step_and_its_inverse(la, T, X, N, eps, beta, B, regime, fused):
+    orc, _, dyn = _pair(T, X, N, eps, B, regime, fused)
+    x, v0f, _, _, _ = H.gauge_inputs(B, 2 * T * X)
+    for step in (0, N - 1):
+        x1, v1, ld = dyn._forward_lf(x, v0f, beta, step)
+        ox, ov, old = orc._forward_lf(x, v0f, beta, step)
+        assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP and H.relerr(np_(ld), old) < TOL_OP
+        xb, vb, ldb = dyn._backward_lf(x, v0f, beta, step)
+        ox, ov, old = orc._backward_lf(x, v0f, beta, step)
+        assert H.relerr(np_(xb), ox) < TOL_OP and H.relerr(np_(vb), ov) < TOL_OP and H.relerr(np_(ldb), old) < TOL_OP
+        # gauge_dynamics.py:537-590: backward inverts forward (index reversed inside _backward_lf)
+        x2, v2, ld2 = dyn._backward_lf(x1, v1, beta, N - 1 - step)
+        assert H.relerr(np_(x2), x) < 2e-5 and H.relerr(np_(v2), v0f) < 2e-5
+        assert H.relerr(np_(ld2), -np_(ld)) < 2e-5
+
+
+@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES)
+def test_transition_kernel_both_directions(la, T, X, N, eps, beta, B, regime, fused):
+    orc, orc32, dyn = _pair(T, X, N, eps, B, regime, fused)
+    x, v0f, v0b, _, _ = H.gauge_inputs(B, 2 * T * X)
+    for fwd, v0 in ((True, v0f), (False, v0b)):
+        xo, vo, p, sld = dyn.transition_kernel(x, beta, forward=fwd, momentum=v0, return_logdet=True)
+        want = orc.transition_kernel(x, beta, v0, forward=fwd)
+        f32 = orc32.transition_kernel(x.astype(np.float32), beta, v0.astype(np.float32), forward=fwd)
+        assert_fp32_equivalent(np_(xo), want[0], f32[0], "x")
+        assert_fp32_equivalent(np_(vo), want[1], f32[1], "v")
+        assert_fp32_equivalent(np_(sld), want[3], f32[3], "sumlogdet")
+        assert np.abs(np_(p) - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+
+
+def test_trajectory_within_1e5_on_benign_dynamics(la):
+    """Small step, near-cold start: the 1e-5 bar holds for the whole 10-step trajectory outright."""
+    T = X = 8
+    N, eps, beta, B = 10, 0.1, 2.0, 40
+    orc, _, dyn = _pair(T, X, N, eps, B, "mild")
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 0.3, (B, 128))
+    v = rng.standard_normal((B, 128))
+    for fwd in (True, False):
+        xo, vo, p, sld = dyn.transition_kernel(x, beta, forward=fwd, momentum=v, return_logdet=True)
+        want = orc.transition_kernel(x, beta, v, forward=fwd)
+        assert H.relerr(np_(xo), want[0]) < TOL_OP and H.relerr(np_(vo), want[1]) < TOL_OP
+        assert np.abs(np_(p) - want[2]).max() < TOL_P and H.relerr(np_(sld), want[3]) < TOL_OP
+        assert want[2].mean() > 0.05       # a regime where proposals actually get accepted
+
+
+@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES[:6])
+def test_apply_transition_matches_oracle_in_both_modes(la, T, X, N, eps, beta, B, regime, fused):
+    orc, orc32, dyn = _pair(T, X, N, eps, B, regime, fused)
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * T * X)
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    f32 = orc32.apply_transition(x.astype(np.float32), beta, v0f.astype(np.float32), v0b.astype(np.float32),
+                                 coin, u.astype(np.float32))
+    outs = {}
+    for both in (True, False):
+        dyn.both_directions = both
+        got = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+        outs[both] = [np_(g) for g in got]
+        assert_fp32_equivalent(outs[both][0], want[0], f32[0], "x_prop")
+        assert_fp32_equivalent(outs[both][1], want[1], f32[1], "v_prop")
+        assert np.abs(outs[both][2] - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+        safe = np.abs(want[2] - u) > 1e-4        # accept decisions can only flip where p - u is within rounding
+        assert_fp32_equivalent(outs[both][3][safe], want[3][safe], f32[3][safe], "x_out")
+        acc = outs[both][2] > u
+        np.testing.assert_array_equal(outs[both][3][acc & safe], outs[both][0][acc & safe])
+        np.testing.assert_array_equal(outs[both][3][~acc & safe], x.astype(np.float32)[~acc & safe])
+    # selected-direction mode returns exactly what both-directions mode returns
+    for a, b in zip(outs[True], outs[False]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_hmc_mode_is_plain_leapfrog(la):
+    T = X = 8
+    N, eps, beta, B = 5, 0.05, 2.0, 20
+    orc, _, dyn = _pair(T, X, N, eps, B, "init", hmc=True)
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, 128)
+    xo, vo, p, sld = dyn.transition_kernel(x, beta, forward=True, momentum=v0f, return_logdet=True)
+    want = orc.transition_kernel(x, beta, v0f, forward=True)
+    assert H.relerr(np_(xo), want[0]) < TOL_OP and H.relerr(np_(vo), want[1]) < TOL_OP
+    assert torch.all(sld == 0) and np.abs(np_(p) - want[2]).max() < 1e-4
+    got = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+    w = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    assert H.relerr(np_(got[0]), w[0]) < TOL_OP and np.abs(np_(got[2]) - w[2]).max() < 1e-4
+
+
+def test_sub_update_methods_on_materialised_stq(la):
+    """The reference's public sub-update methods (gauge_dynamics.py:486-590) through the standalone ops."""
+    T = X = 8
+    orc, _, dyn = _pair(T, X, 4, 0.2, 12, "stress")
+    x, v, _, _, _ = H.gauge_inputs(12, 128)
+    t = dyn._format_time(1, tile=12)
+    to = orc._format_time(1, tile=12)
+    assert H.relerr(np_(t), to) < 1e-6
+    m, mi = dyn._get_mask_while(1)
+    mo, mio = orc._get_mask_while(1)
+    for fn, ofn, args, oargs in (
+            (dyn._update_momentum_forward, orc._update_momentum_forward, (x, v, 2.0, t), (x, v, 2.0, to)),
+            (dyn._update_momentum_backward, orc._update_momentum_backward, (x, v, 2.0, t), (x, v, 2.0, to)),
+            (dyn._update_position_forward, orc._update_position_forward, (x, v, t, m, mi), (x, v, to, mo, mio)),
+            (dyn._update_position_backward, orc._update_position_backward, (x, v, t, mi, m), (x, v, to, mio, mo))):
+        got, ld = fn(*args)
+        want, old = ofn(*oargs)
+        assert H.relerr(np_(got), want) < TOL_OP and H.relerr(np_(ld), old) < TOL_OP
+    h = dyn.hamiltonian(x, v, 2.0)
+    assert H.relerr(np_(h), orc.hamiltonian(x, v, 2.0)) < TOL_OP
+    p = dyn._compute_accept_prob(x, v, x, v, np.zeros(12), 2.0)
+    assert torch.all(p == 1)
+    # non-finite -> 0 (gauge_dynamics.py:609)
+    bad = dyn._compute_accept_prob(x, v, x, v, np.full(12, np.nan), 2.0)
+    assert torch.all(bad == 0)
+
+
+def test_constructor_surface_and_errors(la):
+    lat = la.GaugeLattice(8, 8, 2, 'U1', num_samples=4, rand=True)
+    fn = lat.get_energy_function()
+    d = la.GaugeDynamics(lat, fn, eps=0.3, hmc=False, network_arch='generic', num_steps=3, eps_trainable=True,
+                         data_format='channels_last')
+    assert d.batch_size == 4 and d.x_dim == 128 and abs(float(d.eps) - 0.3) < 1e-7
+    assert d.mask.shape == (3, 128) and torch.all(d.mask.sum(1) == 64)
+    assert len(d.trainable_variables) == 1 + 2 * 16 and d.position_fn.num_hidden == 512
+    out = d(torch.as_tensor(lat.samples.reshape(4, -1)), 2.0)
+    assert [tuple(o.shape) for o in out] == [(4, 128), (4, 128), (4,), (4, 128)]
+    assert torch.all((out[2] >= 0) & (out[2] <= 1))
+    with pytest.raises(AttributeError):      # gauge_dynamics.py:117-119
+        la.GaugeDynamics(lat, fn, eps=0.3, hmc=False, network_arch='bogus', num_steps=3, eps_trainable=True)
+    with pytest.raises(NotImplementedError):
+        la.GaugeDynamics(lat, lambda x: x.sum(1), eps=0.3, hmc=True, num_steps=3, eps_trainable=True)
+    d.position_fn.save_weights("/tmp/_xnet_weights")
+    d.position_fn.load_weights("/tmp/_xnet_weights")
+
+
+# ----------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name,fused", [("gauge_L4_stress", True), ("gauge_L8_cfg3_init", True),
+                                        ("gauge_L8_cfg3_init", False), ("gauge_L8_cfg3_mild", True)])
+def test_golden_gauge(la, name, fused):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    T, X, N = int(g["T"]), int(g["X"]), int(g["num_steps"])
+    if "xnet/h_layer/W" in g.files:
+        xp = {k[5:]: g[k] for k in g.files if k.startswith("xnet/")}
+        vp = {k[5:]: g[k] for k in g.files if k.startswith("vnet/")}
+    else:
+        xp, vp = H.gauge_weights(T, X, seed=106, regime=str(g["regime"]))
+    B = g["x"].shape[0]
+    dyn = H.gauge_hip(T, X, N, float(g["eps"]), xp, vp, g["masks"], B)
+    dyn.fused = fused
+    beta = float(g["beta"])
+    S, Tt, Q = dyn.momentum_fn([g["x"], g["grad0"], dyn._format_time(0)])
+    assert H.relerr(np_(S), g["stq0_S"]) < TOL_OP and H.relerr(np_(Tt), g["stq0_T"]) < TOL_OP
+    assert H.relerr(np_(Q), g["stq0_Q"]) < TOL_OP
+    # step-by-step trace of the forward trajectory
+    x, v = g["x"], g["v0f"]
+    ld = np.zeros(B)
+    tol = TOL_OP
+    for step in range(N):
+        x, v, dl = dyn._forward_lf(x, v, beta, step)
+        ld = ld + np_(dl)
+        tol = tol * (1.0 if name == "gauge_L4_stress" else 1.2)   # error budget grows with the dynamics
+        assert H.relerr(np_(x), g["traj_f/x_steps"][step]) < tol, step
+        assert H.relerr(np_(v), g["traj_f/v_steps"][step]) < tol, step
+        assert H.relerr(ld, g["traj_f/logdet_steps"][step]) < tol, step
+    got = dyn.apply_transition(g["x"], beta, momentum_f=g["v0f"], momentum_b=g["v0b"], coin=g["coin"], u=g["u"])
+    assert H.relerr(np_(got[0]), g["x_prop"]) < 5 * TOL_OP and np.abs(np_(got[2]) - g["p_accept"]).max() < TOL_P
+
+
+# ----------------------------------------------------------------- toy targets / generic Dynamics
+def _small(la, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name.startswith("mog"):
+        tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    else:
+        tgt = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+    nh = int(g["num_nodes"])
+    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=int(g["trajectory_length"]), eps=float(g["eps"]),
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=nh),
+                      use_temperature=True)
+    dyn.set_masks(g["masks"])
+    dyn.XNet.load_state({k[5:]: g[k] for k in g.files if k.startswith("xnet/")})
+    dyn.VNet.load_state({k[5:]: g[k] for k in g.files if k.startswith("vnet/")})
+    return g, tgt, dyn
+
+
+@pytest.mark.parametrize("name", ["mog_cfg2", "scg_cfg1"])
+def test_generic_dynamics_and_propose(la, name):
+    g, tgt, dyn = _small(la, name)
+    x = g["x"]
+    assert H.relerr(np_(dyn.energy(x)), g["energy"]) < 2e-5       # SCG: ill-conditioned precision (cond 1e3)
+    assert H.relerr(np_(dyn.grad_energy(x)), g["grad_energy"]) < TOL_OP
+    Xf, Vf, pf = dyn.forward(x, init_v=g["v0f"])
+    Xb, Vb, pb = dyn.backward(x, init_v=g["v0b"])
+    for got, key in ((Xf, "Xf"), (Vf, "Vf"), (Xb, "Xb"), (Vb, "Vb")):
+        assert H.relerr(np_(got), g[key]) < TOL_OP, key
+    assert np.abs(np_(pf) - g["pf"]).max() < TOL_P and np.abs(np_(pb) - g["pb"]).max() < TOL_P
+    Lx, Lv, px, outs = la.propose(x, dyn, init_v=g["v0f"], do_mh_step=True, init_v_backward=g["v0b"],
+                                  dir_bits=g["dir_bits"], u=g["u"])
+    assert H.relerr(np_(Lx), g["Lx"]) < TOL_OP and H.relerr(np_(Lv), g["Lv_mixed"]) < TOL_OP
+    assert np.abs(np_(px) - g["px"]).max() < TOL_P
+    safe = np.abs(g["px"] - g["u"]) > 1e-4
+    assert H.relerr(np_(outs[0])[safe], g["x_accept"][safe]) < TOL_OP
+    # init_v=None -> Lv is None (sampler.py:43-45), momenta drawn on the device
+    Lx2, Lv2, px2, outs2 = la.propose(x, dyn, do_mh_step=False)
+    assert Lv2 is None and outs2 == [] and torch.all((px2 >= 0) & (px2 <= 1))
+    # log_jac=True returns the log-Jacobian instead of p
+    X3, V3, lj = dyn.forward(x, init_v=g["v0f"], log_jac=True)
+    assert torch.equal(X3, Xf)
+    # temperature divides the energy (utils/dynamics.py:227-236)
+    dyn.temperature = 2.0
+    assert H.relerr(np_(dyn.energy(x)), g["energy"] / 2.0) < 2e-5
+    with pytest.raises(TypeError):
+        la.Dynamics(2, lambda x: x.sum(1), trajectory_length=3, eps=0.1, net_factory=la.network)
+
+
+def test_generic_dynamics_hmc_and_quadratic_gaussian(la):
+    tgt = la.Gaussian(np.zeros(2), np.array([[1.0, 0.3], [0.3, 0.5]]))
+    ot = ogen.Gaussian(np.zeros(2), np.array([[1.0, 0.3], [0.3, 0.5]]))
+    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=4, eps=0.05, hmc=True)
+    rng = np.random.default_rng(3)
+    x, v = rng.standard_normal((50, 2)), rng.standard_normal((50, 2))
+    orc = ogen.DynamicsOracle(2, ot, 4, 0.05, np_(dyn.mask), hmc=True)
+    X, V, p = dyn.forward(x, init_v=v)
+    want = orc.forward(x, v)
+    assert H.relerr(np_(X), want[0]) < TOL_OP and H.relerr(np_(V), want[1]) < TOL_OP
+    assert np.abs(np_(p) - want[2]).max() < TOL_P
+    q = la.quadratic_gaussian(x, np.zeros(2), ot.i_sigma)
+    assert H.relerr(np_(q), ogen.quadratic_gaussian(x, np.zeros(2), ot.i_sigma.astype('float32').astype(float))) < TOL_OP
+
+
+# ----------------------------------------------------------------- RNG
+def _philox_ref(block, offset, seed):
+    """Philox4x32-10 in Python integers (Salmon et al., SC'11), for the bit-exact check."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [block & 0xFFFFFFFF, block >> 32, offset & 0xFFFFFFFF, offset >> 32]
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    for _ in range(10):
+        p0, p1 = c[0] * M0, c[2] * M1
+        c = [(p1 >> 32) ^ c[1] ^ k0, p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k1, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c
+
+
+def test_philox_stream_bit_exact_and_statistics(la):
+    from l2hmc_amd import _lib
+    # Random123 known-answer vector: counter = key = 0
+    assert _philox_ref(0, 0, 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    n = 4096 + 3                         # ragged tail
+    u = torch.empty(n, device="cuda")
+    for seed, off in ((0, 0), (12345678901234, 77)):
+        _lib.check(_lib.lib().l2hmc_fill_uniform(u.data_ptr(), n, seed, off, None))
+        got = u.cpu().numpy()
+        for i in (0, 1, 2, 3, 4, 1001, n - 1):
+            w = _philox_ref(i >> 2, off, seed)[i & 3]
+            assert got[i] == np.float32((w >> 8) * 2.0 ** -24)      # integer work: bit-exact
+    z = torch.empty(1 << 20, device="cuda")
+    _lib.check(_lib.lib().l2hmc_fill_normal(z.data_ptr(), z.numel(), 7, 0, None))
+    zz = z.double().cpu().numpy()
+    assert abs(zz.mean()) < 5e-3 and abs(zz.std() - 1) < 5e-3 and np.isfinite(zz).all()
+    assert abs((zz ** 4).mean() - 3.0) < 0.05 and abs(np.corrcoef(zz[::2], zz[1::2])[0, 1]) < 5e-3
+    z2 = torch.empty_like(z)
+    _lib.check(_lib.lib().l2hmc_fill_normal(z2.data_ptr(), z2.numel(), 7, 0, None))
+    assert torch.equal(z, z2)            # same (seed, offset) -> same stream
+    _lib.check(_lib.lib().l2hmc_fill_normal(z2.data_ptr(), z2.numel(), 7, 1, None))
+    assert not torch.equal(z, z2)
+
+
+# ----------------------------------------------------------------- full size (BASELINE.json configs[2])
+def test_full_size_properties_cfg3(la):
+    """B=2048, 10 LF steps: size-independent properties instead of an oracle run."""
+    T = X = 8
+    N, eps, beta, B = 10, 0.25, 2.0, 2048
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    masks = H.gauge_oracle(T, X, N, eps, xp, vp).mask
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, masks, B)
+    x = torch.rand(B, 128, device="cuda") * (2 * np.pi)
+    v = torch.randn(B, 128, device="cuda")
+    # (1) reversibility: backward trajectory undoes the forward one, log-dets cancel
+    x1, v1, p1, ld1 = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+    x2, v2, p2, ld2 = dyn.transition_kernel(x1, beta, forward=False, momentum=v1, return_logdet=True)
+    # (20 chaotic steps there and back: rounding noise is amplified twice; 1e-3 still pins the inverse)
+    assert H.relerr(np_(x2), np_(x)) < 1e-3 and H.relerr(np_(v2), np_(v)) < 1e-3
+    assert H.relerr(np_(ld2), -np_(ld1)) < 1e-3
+    # (2) determinism + fused == layered on identical inputs
+    x1b, v1b, p1b, _ = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+    assert torch.equal(x1, x1b) and torch.equal(p1, p1b)
+    dyn.fused = False
+    x1c, v1c, p1c, ld1c = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+    assert H.relerr(np_(x1c), np_(x1)) < 5e-5 and np.abs(np_(p1c) - np_(p1)).max() < 1e-4
+    dyn.fused = True
+    # (3) first 64 chains agree with the oracle; p in [0, 1]
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    orc32 = H.gauge_oracle(T, X, N, eps, xp, vp, dtype=np.float32)
+    xs, vs = np_(x[:64]), np_(v[:64])
+    want = orc.transition_kernel(xs, beta, vs, forward=True)
+    w32 = orc32.transition_kernel(xs.astype(np.float32), beta, vs.astype(np.float32), forward=True)
+    assert_fp32_equivalent(np_(x1[:64]), want[0], w32[0], "x (first 64 chains)")
+    assert torch.all((p1 >= 0) & (p1 <= 1))
+    # (4) a whole MCMC step with device-side draws: outputs are either the proposal or the input
+    out = dyn(x, beta)
+    same = (out[3] == x).all(1) | (out[3] == out[0]).all(1)
+    assert bool(same.all())

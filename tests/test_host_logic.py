@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: weight packing layout, mask / time
+construction, chain sharding, golden fixtures vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, lattice as olat, dynamics as ogen
+from oracle.gauge_dynamics import make_masks
+from l2hmc_amd.network import GenericNet, MLPNet
+from l2hmc_amd.dist import shard_bounds
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_generic_net_packing_layout_matches_reference_dense_layout():
+    rng = np.random.default_rng(0)
+    D, Hd = 32, 128
+    p = nets.init_generic_net(rng, D, Hd, 2., bias_std=0.1, coeff_std=0.1)
+    net = GenericNet(model_name='XNet', device=torch.device("cpu"), x_dim=D, num_hidden=Hd, factor=2.,
+                     name_scope='position', links_shape=(4, 4, 2))
+    net.load_state(p)
+    b = {k: v.numpy() for k, v in net._pack_tensors().items()}
+    f32 = lambda a: np.asarray(a, dtype=np.float32)  # noqa: E731
+    # first input -> v_layer, second -> x_layer (generic_net.py:129-135); k-contiguous rows
+    np.testing.assert_array_equal(b["w1_t"][:, :D], f32(p['v_layer/W']).T)
+    np.testing.assert_array_equal(b["w1_t"][:, D:], f32(p['x_layer/W']).T)
+    np.testing.assert_allclose(b["b1"], f32(p['v_layer/b']) + f32(p['x_layer/b']) + f32(p['t_layer/b']), rtol=1e-6)
+    np.testing.assert_array_equal(b["wt"], f32(p['t_layer/W']))
+    np.testing.assert_array_equal(b["wh_t"], f32(p['h_layer/W']).T)
+    for i, name in enumerate(('scale_layer', 'translation_layer', 'transformation_layer')):
+        np.testing.assert_array_equal(b["whd_t"][i], f32(p[name + '/W']).T)
+        np.testing.assert_array_equal(b["bhd"][i], f32(p[name + '/b']))
+    np.testing.assert_array_equal(b["coeff_s"], f32(p['coeff_scale'])[0])
+    # a matmul through the packed form equals the oracle's layer-by-layer form
+    v, x = rng.standard_normal((5, D)), rng.standard_normal((5, D))
+    h_packed = np.concatenate([v, x], 1) @ b["w1_t"].T.astype(np.float64)
+    h_ref = v @ p['v_layer/W'] + x @ p['x_layer/W']
+    np.testing.assert_allclose(h_packed, h_ref, atol=1e-5)
+
+
+def test_reference_initialisation_statistics():
+    # generic_net.py:149-161: truncated normal, std = sqrt(1.3 * 2 f / fan_in), zero bias, zero coeffs
+    net = GenericNet(model_name='VNet', device=torch.device("cpu"), rng=np.random.RandomState(1), x_dim=128,
+                     num_hidden=512, factor=1., name_scope='momentum', links_shape=(8, 8, 2))
+    W = net.h_layer.kernel.numpy()
+    std = np.sqrt(1.3 * 2. / 512)
+    assert np.abs(W).max() <= 2 * std + 1e-7
+    assert abs(W.std() / (std * 0.8796) - 1) < 0.02          # std of a 2-sigma truncated normal
+    assert net.scale_layer.kernel.abs().max() <= 2 * np.sqrt(1.3 * 0.002 / 512) + 1e-9
+    assert float(net.h_layer.bias.abs().sum()) == 0 and float(net.coeff_scale.abs().sum()) == 0
+    assert len(net.variables) == 16 and net.q_tanh == 0
+    m = MLPNet(2, 'XNet', 2.0, 50, device=torch.device("cpu"))
+    assert m.q_tanh == 1 and m.embed_2.kernel.shape == (2, 50) and m.linear_f.kernel.shape == (50, 2)
+
+
+def test_mask_and_time_tables_follow_reference_streams():
+    np.random.seed(42)
+    a = make_masks(10, 128)                       # global legacy stream, gauge_dynamics.py:651-661
+    b = make_masks(10, 128, np.random.RandomState(42))
+    np.testing.assert_array_equal(a, b)
+    np.random.seed(42)
+    c = ogen.make_masks(10, 128)                  # utils/dynamics.py:85-96 draws the same stream
+    np.testing.assert_array_equal(a, c)
+    assert a.sum() == 10 * 64 and set(np.unique(a)) == {0.0, 1.0}
+
+
+def test_shard_bounds_partition_the_chains():
+    for n, w in ((2048, 8), (8192, 8), (10, 3), (5, 8), (0, 2)):
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 == b0 and a0 <= a1
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+# ------------------------------------------------------------- golden fixtures vs the oracle
+def _npz(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def test_golden_u1_observables():
+    g = _npz("u1_obs")
+    for (T, X) in ((8, 8), (4, 6)):
+        k = f"{T}x{X}"
+        x = g[k + "/x"]
+        np.testing.assert_allclose(olat.plaq_sums(x, T, X), g[k + "/plaq_sums"], atol=1e-13)
+        np.testing.assert_allclose(olat.total_action(x, T, X), g[k + "/action"], atol=1e-12)
+        np.testing.assert_allclose(2.5 * olat.grad_action(x, T, X), g[k + "/force_beta2.5"], atol=1e-13)
+        np.testing.assert_allclose(olat.top_charge(x, T, X), g[k + "/top_charge"], atol=1e-12)
+
+
+def _gauge_oracle_from_fixture(g):
+    T, X, N = int(g["T"]), int(g["X"]), int(g["num_steps"])
+    if "xnet/h_layer/W" in g.files:
+        xp = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith("xnet/")}
+        vp = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith("vnet/")}
+    else:
+        xp, vp = H.gauge_weights(T, X, seed=106, regime=str(g["regime"]))
+        wsum = lambda p: np.array([[np.sum(v), np.sum(np.abs(v))] for _, v in sorted(p.items())])  # noqa: E731
+        # the seeded initialiser must reproduce the weights the fixture was made with
+        np.testing.assert_allclose(wsum(xp), g["xnet_checksum"], rtol=1e-12)
+        np.testing.assert_allclose(wsum(vp), g["vnet_checksum"], rtol=1e-12)
+    orc = H.gauge_oracle(T, X, N, float(g["eps"]), xp, vp)
+    np.testing.assert_array_equal(orc.mask, g["masks"])
+    return orc, xp, vp
+
+
+@pytest.mark.parametrize("name", ["gauge_L4_stress", "gauge_L8_cfg3_init", "gauge_L8_cfg3_mild"])
+def test_golden_gauge_trajectories(name):
+    g = _npz(name)
+    orc, _, _ = _gauge_oracle_from_fixture(g)
+    beta = float(g["beta"])
+    trace = []
+    orc.transition_kernel(g["x"], beta, g["v0f"], forward=True, trace=trace)
+    np.testing.assert_allclose(np.stack([t[0] for t in trace]), g["traj_f/x_steps"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.stack([t[2] for t in trace]), g["traj_f/logdet_steps"], rtol=1e-9, atol=1e-9)
+    out = orc.apply_transition(g["x"], beta, g["v0f"], g["v0b"], g["coin"], g["u"])
+    for got, key in zip(out, ("x_prop", "v_prop", "p_accept", "x_out")):
+        np.testing.assert_allclose(got, g[key], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,target", [("mog_cfg2", "mog"), ("scg_cfg1", "scg")])
+def test_golden_small_targets(name, target):
+    g = _npz(name)
+    tgt = H.mog_target_oracle() if target == "mog" else H.scg_target_oracle()
+    xp = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith("xnet/")}
+    vp = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith("vnet/")}
+    orc = ogen.DynamicsOracle(2, tgt, int(g["trajectory_length"]), float(g["eps"]), g["masks"], xp, vp)
+    np.testing.assert_allclose(tgt.energy(g["x"]), g["energy"], rtol=1e-10, atol=1e-10)
+    Xf, Vf, pf = orc.forward(g["x"], g["v0f"])
+    np.testing.assert_allclose(Xf, g["Xf"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(pf, g["pf"], rtol=1e-9, atol=1e-12)
+    Lx, Lv, px, outs, _ = ogen.propose(g["x"], orc, g["v0f"], g["v0b"], g["dir_bits"], g["u"], do_mh_step=True)
+    np.testing.assert_allclose(outs[0], g["x_accept"], rtol=1e-9, atol=1e-9)
