@@ -30,15 +30,21 @@ namespace l2hmc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kFM = 16;          // rows per workgroup
-constexpr int kFThreads = 256;   // 4 waves; wave w owns output columns [w*N/4, (w+1)*N/4)
+constexpr int kFM = 16;                   // rows per workgroup
+#ifndef L2HMC_FUSED_WAVES
+#define L2HMC_FUSED_WAVES 4
+#endif
+constexpr int kFWaves = L2HMC_FUSED_WAVES;   // waves per workgroup (4 = one per SIMD, 8 = two per SIMD)
+constexpr int kFThreads = 64 * kFWaves;   // wave w owns output columns [w*N/kFWaves, (w+1)*N/kFWaves)
+constexpr int kTPC = kFThreads / kFM;     // threads per chain in the chain-local passes
 
 template <int D, int H>
 struct FusedCfg {
   static constexpr int SX = D + 8;             // LDS row stride of x / v / second-input rows
   static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
-  static constexpr int NT1 = H / 64;           // 16-column tiles per wave, layers 1 and 2
-  static constexpr int NTH = D / 64;           // tiles per wave per head
+  static constexpr int NT1 = H / (16 * kFWaves);   // 16-column tiles per wave, layers 1 and 2
+  static constexpr int NTH = D / (16 * kFWaves);   // tiles per wave per head
+  static_assert(NT1 >= 1 && NTH >= 1, "every wave needs at least one tile per layer");
   static constexpr int KC1 = 2 * D / 16;       // k-chunks (16 k each), layer 1
   static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
   static constexpr size_t P1 = (size_t)2 * D * H;   // packed floats per section
@@ -47,8 +53,18 @@ struct FusedCfg {
   // per-net constants kept in LDS: b1[H] wt[2H] bh[H] bhd[3D] exp(cs)[D] exp(cq)[D]
   static constexpr int NC = 4 * H + 5 * D;
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
-                                    2 * D /*masks*/ + 4 * kFM /*ldw*/ + kFM /*dir*/;
+                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/;
 };
+
+// exp / tanh on the hardware exp2 + rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Arguments here are
+// eps * S, eps * Q and pre-activations of O(1): |error| <= ~2e-7 relative for exp, ~1.5e-7 absolute for
+// tanh -- at the fp32 rounding floor of the quantities they feed, and ~8x cheaper than the libm forms.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(x));      // exp(-2|x|) in (0, 1]
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, x);
+}
 
 // ---------------------------------------------------------------------------
 // weight packing (device side, once per weight update)
@@ -56,7 +72,7 @@ struct FusedCfg {
 __global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out) {
   const int D = n.D, H = n.H, K1 = n.Ka + n.Kb;
   const size_t P1 = (size_t)K1 * H, P2 = (size_t)H * H, PH = (size_t)3 * D * H;
-  const int NT1 = H / 64, NTH = D / 64;
+  const int NT1 = H / (16 * kFWaves), NTH = D / (16 * kFWaves);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P1 + P2 + PH;
        i += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
@@ -81,7 +97,7 @@ __global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out) {
       rest /= 3;
       const int KC = H / 16;
       const int kc = (int)(rest % KC), w = (int)(rest / KC);
-      const int col = w * (D / 4) + t * 16 + (lane & 15);
+      const int col = w * (D / kFWaves) + t * 16 + (lane & 15);
       const int k = kc * 16 + (lane >> 4) * 4 + j;
       val = n.whd_t[((size_t)hd * D + col) * H + k];
     }
@@ -106,23 +122,63 @@ __device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restri
   for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
 }
 
-// wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc.
-template <int NT, int NKC, typename AF>
-__device__ __forceinline__ void stream_layer(const float* __restrict__ wp, AF afrag, f32x4 (&acc)[NT]) {
-  static_assert(NKC % 2 == 0, "k-chunks are consumed in pairs");
-  f32x4 b0[NT], b1[NT];
-  load_frags<NT>(b0, wp, 0);
-  load_frags<NT>(b1, wp, 1);
-#pragma nounroll
-  for (int kc = 0; kc < NKC; kc += 2) {
-    f32x4 a = afrag(kc);
-    mfma_block<NT>(a, b0, acc);
-    if (kc + 2 < NKC) load_frags<NT>(b0, wp, kc + 2);
-    a = afrag(kc + 1);
-    mfma_block<NT>(a, b1, acc);
-    if (kc + 3 < NKC) load_frags<NT>(b1, wp, kc + 3);
-  }
+// Three-deep ring of B fragments: chunk kc+3 is requested as soon as chunk kc has been consumed, so every
+// load has two full MFMA blocks (~2 x 32 x NT cycles) to come back from L2.  The ring of the NEXT layer is
+// primed before the current layer's epilogue and barrier, which hides the pipeline fill.
+template <int NT>
+struct BRing {
+  f32x4 b[3][NT];
+};
+
+template <int NT>
+__device__ __forceinline__ void ring_prime(BRing<NT>& R, const float* __restrict__ wp) {
+  load_frags<NT>(R.b[0], wp, 0);
+  load_frags<NT>(R.b[1], wp, 1);
+  load_frags<NT>(R.b[2], wp, 2);
 }
+
+// wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
+// (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
+template <int NT, int NKC, typename AF>
+__device__ __forceinline__ void stream_layer(BRing<NT>& R, const float* __restrict__ wp, AF afrag,
+                                             f32x4 (&acc)[NT]) {
+  static_assert(NKC >= 3, "ring depth");
+  f32x4 a0 = afrag(0), a1;
+  int kc = 0;
+#pragma nounroll
+  for (; kc + 3 <= NKC; kc += 3) {
+    a1 = afrag(kc + 1 < NKC ? kc + 1 : NKC - 1);
+    mfma_block<NT>(a0, R.b[0], acc);
+    if (kc + 3 < NKC) load_frags<NT>(R.b[0], wp, kc + 3);
+    a0 = afrag(kc + 2 < NKC ? kc + 2 : NKC - 1);
+    mfma_block<NT>(a1, R.b[1], acc);
+    if (kc + 4 < NKC) load_frags<NT>(R.b[1], wp, kc + 4);
+    a1 = afrag(kc + 3 < NKC ? kc + 3 : NKC - 1);
+    mfma_block<NT>(a0, R.b[2], acc);
+    if (kc + 5 < NKC) load_frags<NT>(R.b[2], wp, kc + 5);
+    a0 = a1;
+  }
+  if constexpr (NKC % 3 >= 1) {
+    if constexpr (NKC % 3 == 2) a1 = afrag(NKC - 1);
+    mfma_block<NT>(a0, R.b[0], acc);
+  }
+  if constexpr (NKC % 3 == 2) mfma_block<NT>(a1, R.b[1], acc);
+}
+
+#ifdef L2HMC_STAMPS
+#define FT_NOW()                                                                              \
+  ({                                                                                          \
+    unsigned long long t_;                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    t_;                                                                                       \
+  })
+#define FT_ADD(slot, t0) ft[slot] += FT_NOW() - (t0)
+#else
+#define FT_NOW() 0ull
+#define FT_ADD(slot, t0) do {} while (0)
+#endif
 
 struct FusedArgs {
   int T, X, num_steps, step_begin, step_end;
@@ -136,7 +192,14 @@ struct FusedArgs {
   float* logdet;                         // [rows] or NULL; written (=) or accumulated (+=)
   int logdet_accumulate;
   float* p_accept;                       // [rows] or NULL
+  unsigned long long* stamps;            // diagnostic builds only
+  int stagger;                           // cycles of start delay per in-XCD workgroup index (0 = none)
 };
+
+#ifdef L2HMC_STAMPS
+int g_fused_stagger = 0;
+extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; }
+#endif
 
 template <int D, int H>
 __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p) {
@@ -154,9 +217,16 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   float* cv = cx + Cfg::NC;                // VNet constants [NC]
   float* sp = cv + Cfg::NC;                // [16][SP] sin P
   float* skm = sp + kFM * SP;              // [2][D]  masks of this step: forward row, backward row
-  float* ldw = skm + 2 * D;                // [4][16] log-det partial sums per wave
-  int* sdir = reinterpret_cast<int*>(ldw + 4 * kFM);   // [16]
+  float* ldw = skm + 2 * D;                // [waves][16] log-det partial sums per wave
+  int* sdir = reinterpret_cast<int*>(ldw + kFWaves * kFM);   // [16]
 
+  // diagnostic cycle shares: 0-2 gemm L1/L2/heads, 3-5 their epilogues, 6 barriers, 7 force, 8 mask pass, 9 total
+  [[maybe_unused]] unsigned long long ft[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] const unsigned long long ft_start = FT_NOW();
+#ifdef L2HMC_STAMPS
+  unsigned long long rt0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
@@ -164,6 +234,12 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   const int nrow = (int)min((int64_t)kFM, p.rows - row0);
   const float eps = p.eps;
 
+  if (p.stagger > 0) {
+    // spread the workgroups of an XCD (blockIdx & 7 labels the XCD group) over the weight stream in time
+    const long long delay = (long long)((blockIdx.x >> 3) & 31) * p.stagger;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
+  }
   // ---- stage chain state and constants ------------------------------------
   for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
     const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
@@ -191,21 +267,26 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   load_consts(p.xnet, cx);
   load_consts(p.vnet, cv);
   if (tid < kFM) sdir[tid] = (p.dir && tid < nrow) ? p.dir[row0 + tid] : 0;
-  if (tid < 4 * kFM) ldw[tid] = 0.f;
+  if (tid < kFWaves * kFM) ldw[tid] = 0.f;
   __syncthreads();
 
   int dirr[4];                        // direction of the 4 rows this lane owns in a C fragment
 #pragma unroll
   for (int e = 0; e < 4; ++e) dirr[e] = sdir[q * 4 + e];
 
-  // ---- chain-local passes: 16 threads per chain -----------------------------
-  const int fc = tid >> 4, fl = tid & 15;          // chain, lane-in-chain
+  // ---- chain-local passes: kTPC consecutive threads per chain ------------------
+  const int fc = tid / kTPC, fl = tid % kTPC;      // chain, lane-in-chain
+  auto chain_sum = [&](float v) {
+#pragma unroll
+    for (int off = kTPC / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
   const int T = p.T, X = p.X;
   // force (beta * dS/dx) into gs; returns this chain's action (all 16 lanes of the chain)
   auto force_pass = [&]() -> float {
     const float* xc = xs + fc * SX;
     float act = 0.f;
-    for (int s = fl; s < sites; s += 16) {
+    for (int s = fl; s < sites; s += kTPC) {
       const int i = s / X, j = s - i * X;
       const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
       const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
@@ -214,14 +295,11 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       sp[fc * SP + s] = sn;
       act += 1.f - cs;
     }
-    act += __shfl_xor(act, 8, 64);
-    act += __shfl_xor(act, 4, 64);
-    act += __shfl_xor(act, 2, 64);
-    act += __shfl_xor(act, 1, 64);
+    act = chain_sum(act);
     __syncthreads();
     float* gc = gs + fc * SX;
     const float* spc = sp + fc * SP;
-    for (int s = fl; s < sites; s += 16) {
+    for (int s = fl; s < sites; s += kTPC) {
       const int i = s / X, j = s - i * X;
       const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
       const float sP = spc[s];
@@ -234,12 +312,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   auto kinetic_pass = [&]() -> float {
     const float* vc = vs + fc * SX;
     float k = 0.f;
-    for (int d = fl; d < D; d += 16) k += vc[d] * vc[d];
-    k += __shfl_xor(k, 8, 64);
-    k += __shfl_xor(k, 4, 64);
-    k += __shfl_xor(k, 2, 64);
-    k += __shfl_xor(k, 1, 64);
-    return 0.5f * k;
+    for (int d = fl; d < D; d += kTPC) k += vc[d] * vc[d];
+    return 0.5f * chain_sum(k);
   };
 
   const float act0 = force_pass();     // also leaves the force of x0 in gs
@@ -249,23 +323,33 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   // in1: first input rows (LDS, stride SX); second input is always gs.
   // mode 1: momentum update (uses gs as the force), mode 2: position update with keep masks.
   auto net_update = [&](const l2hmc_dense_net& net, const float* cn, const float* in1, int mode, int sub,
-                        const float (&tcr)[4], const float (&tsr)[4]) {
+                        bool prep_next_mask, const float (&tcr)[4], const float (&tsr)[4]) {
     const float* pk = net.packed;
+    const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
+    const float* wp2 = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
+    const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
+    BRing<NT1> R2;
+    BRing<3 * NTH> R3;
     // ----- layer 1
     {
       f32x4 acc[NT1];
 #pragma unroll
       for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* wp = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
+      BRing<NT1> R1;
+      ring_prime<NT1>(R1, wp1);
       const float* a1 = in1 + r * SX + q * 4;
       const float* a2 = gs + r * SX + q * 4;
+      [[maybe_unused]] unsigned long long t0 = FT_NOW();
       stream_layer<NT1, Cfg::KC1>(
-          wp,
+          R1, wp1,
           [&](int kc) {
             const float* src = kc < D / 16 ? a1 + kc * 16 : a2 + (kc - D / 16) * 16;
             return *reinterpret_cast<const f32x4*>(src);
           },
           acc);
+      ring_prime<NT1>(R2, wp2);      // layer-2 weights start flowing under the epilogue + barrier
+      FT_ADD(0, t0);
+      t0 = FT_NOW();
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
         const int col = (wave * NT1 + t) * 16 + r;
@@ -274,17 +358,25 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
         for (int e = 0; e < 4; ++e)
           h1[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b + (tcr[e] * w0 + tsr[e] * w1), 0.f);
       }
+      FT_ADD(3, t0);
     }
-    __syncthreads();
+    {
+      [[maybe_unused]] const unsigned long long tb = FT_NOW();
+      __syncthreads();
+      FT_ADD(6, tb);
+    }
     // ----- layer 2
     {
       f32x4 acc[NT1];
 #pragma unroll
       for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* wp = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
       const float* a = h1 + r * SH + q * 4;
+      [[maybe_unused]] unsigned long long t0 = FT_NOW();
       stream_layer<NT1, Cfg::KC2>(
-          wp, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+          R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+      ring_prime<3 * NTH>(R3, wph);
+      FT_ADD(1, t0);
+      t0 = FT_NOW();
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
         const int col = (wave * NT1 + t) * 16 + r;
@@ -292,24 +384,31 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
 #pragma unroll
         for (int e = 0; e < 4; ++e) h2[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b, 0.f);
       }
+      FT_ADD(4, t0);
     }
-    __syncthreads();
+    {
+      [[maybe_unused]] const unsigned long long tb = FT_NOW();
+      __syncthreads();
+      FT_ADD(6, tb);
+    }
     // ----- heads + update
     {
       f32x4 acc[3 * NTH];
 #pragma unroll
       for (int t = 0; t < 3 * NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* wp = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
       const float* a = h2 + r * SH + q * 4;
+      [[maybe_unused]] unsigned long long t0 = FT_NOW();
       stream_layer<3 * NTH, Cfg::KC2>(
-          wp, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+          R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+      FT_ADD(2, t0);
+      t0 = FT_NOW();
       float ld[4] = {0.f, 0.f, 0.f, 0.f};
       const float* bhd = cn + 4 * H;
       const float* es = bhd + 3 * D;
       const float* eq = es + D;
 #pragma unroll
       for (int t = 0; t < NTH; ++t) {
-        const int col = wave * (D / 4) + t * 16 + r;
+        const int col = wave * (D / kFWaves) + t * 16 + r;
         const float b_s = bhd[col], b_t = bhd[D + col], b_q = bhd[2 * D + col];
         const float e_s = es[col], e_q = eq[col];
         const float mf = skm[col], mb = skm[D + col];
@@ -317,27 +416,37 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
         for (int e = 0; e < 4; ++e) {
           const int row = q * 4 + e;
           const int d = dirr[e];
-          const float S = tanhf(acc[0 * NTH + t][e] + b_s) * e_s;
+          const float S = fast_tanh(acc[0 * NTH + t][e] + b_s) * e_s;
           const float Tt = acc[1 * NTH + t][e] + b_t;
           float Q = acc[2 * NTH + t][e] + b_q;
-          Q = (net.q_tanh ? tanhf(Q) : Q) * e_q;
+          Q = (net.q_tanh ? fast_tanh(Q) : Q) * e_q;
           const int idx = row * SX + col;
           if (mode == 1) {
             // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
             const float g = gs[idx], v = vs[idx];
             const float s = (d ? -0.5f : 0.5f) * eps * S;
-            const float kick = 0.5f * eps * (expf(eps * Q) * g - Tt);
-            vs[idx] = d ? expf(s) * (v + kick) : v * expf(s) - kick;
+            const float kick = 0.5f * eps * (fast_exp(eps * Q) * g - Tt);
+            const float es_ = fast_exp(s);
+            vs[idx] = d ? es_ * (v + kick) : v * es_ - kick;
             ld[e] += s;
+            // the next net call is the first position sub-update: its second input is keep (.) x
+            if (prep_next_mask) {
+              const float k0 = d ? 1.f - mb : mf;
+              gs[idx] = k0 * xs[idx];
+            }
           } else {
             // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd); keep mask per direction and sub-update
             const float keep = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf);
             const float x = xs[idx], v = vs[idx];
             const float s = (d ? -eps : eps) * S;
-            const float drift = eps * (expf(eps * Q) * v + Tt);
-            const float upd = d ? expf(s) * (x - drift) : x * expf(s) + drift;
-            xs[idx] = keep * x + (1.f - keep) * upd;
+            const float drift = eps * (fast_exp(eps * Q) * v + Tt);
+            const float es_ = fast_exp(s);
+            const float upd = d ? es_ * (x - drift) : x * es_ + drift;
+            const float xn = keep * x + (1.f - keep) * upd;
+            xs[idx] = xn;
             ld[e] += (1.f - keep) * s;
+            // second sub-update follows: its keep mask is the complement (gauge_dynamics.py:434-437, :472-475)
+            if (prep_next_mask) gs[idx] = (1.f - keep) * xn;
           }
         }
       }
@@ -350,8 +459,13 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
         t += __shfl_xor(t, 1, 64);
         if (r == 0) ldw[wave * kFM + q * 4 + e] += t;
       }
+      FT_ADD(5, t0);
     }
-    __syncthreads();
+    {
+      [[maybe_unused]] const unsigned long long tb = FT_NOW();
+      __syncthreads();
+      FT_ADD(6, tb);
+    }
   };
 
   // ---- leapfrog steps -----------------------------------------------------------
@@ -372,28 +486,24 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     }
     // (gs holds the force of the current x: from the prologue or the previous step's last kick)
     __syncthreads();
-    net_update(p.vnet, cv, xs, 1, 0, tcr, tsr);               // momentum half-kick
-    for (int sub = 0; sub < 2; ++sub) {
-      // second input of XNet: keep (.) x   (gauge_dynamics.py:515-517)
-      for (int i = tid; i < kFM * D; i += kFThreads) {
-        const int rr = i / D, c = i - rr * D;
-        const int d = sdir[rr];
-        const float mf = skm[c], mb = skm[D + c];
-        const float keep = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf);
-        gs[rr * SX + c] = keep * xs[rr * SX + c];
-      }
-      __syncthreads();
-      net_update(p.xnet, cx, vs, 2, sub, tcr, tsr);           // position sub-update
+    net_update(p.vnet, cv, xs, 1, 0, true, tcr, tsr);         // momentum half-kick (+ keep (.) x into gs)
+    net_update(p.xnet, cx, vs, 2, 0, true, tcr, tsr);         // position sub-update 1 (+ complement mask)
+    net_update(p.xnet, cx, vs, 2, 1, false, tcr, tsr);        // position sub-update 2
+    {
+      [[maybe_unused]] const unsigned long long tf = FT_NOW();
+      (void)force_pass();                                      // force at the new position
+      FT_ADD(7, tf);
     }
-    (void)force_pass();                                        // force at the new position
-    net_update(p.vnet, cv, xs, 1, 0, tcr, tsr);               // second momentum half-kick
+    net_update(p.vnet, cv, xs, 1, 0, false, tcr, tsr);        // second momentum half-kick
   }
 
   // ---- epilogue: energies, accept probability, write back -------------------------
   const float act1 = force_pass();
   const float kin1 = kinetic_pass();
   if (fl == 0 && fc < nrow) {
-    const float sld = ((ldw[fc] + ldw[kFM + fc]) + ldw[2 * kFM + fc]) + ldw[3 * kFM + fc];
+    float sld = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFWaves; ++w) sld += ldw[w * kFM + fc];      // fixed order: bit-reproducible
     const int64_t rr = row0 + fc;
     if (p.logdet) p.logdet[rr] = p.logdet_accumulate ? p.logdet[rr] + sld : sld;
     if (p.p_accept) {
@@ -403,6 +513,16 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       p.p_accept[rr] = accept_from_delta(dh);
     }
   }
+#ifdef L2HMC_STAMPS
+  if (p.stamps && tid == 0) {
+    unsigned long long rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    ft[9] = FT_NOW() - ft_start;
+    for (int i = 0; i < 10; ++i) p.stamps[blockIdx.x * 12 + i] = ft[i];
+    p.stamps[blockIdx.x * 12 + 10] = rt0;
+    p.stamps[blockIdx.x * 12 + 11] = rt1;
+  }
+#endif
   for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
     const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
     if (rr < nrow) {
@@ -444,6 +564,10 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
   a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
+#ifdef L2HMC_STAMPS
+  a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
+  a.stagger = g_fused_stagger;
+#endif
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
   hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512>), grid, dim3(kFThreads), lds, stream, a);

@@ -46,6 +46,7 @@ struct HeadsArgs {
 // -DL2HMC_STAMPS, never in the shipped library.  Slot layout per workgroup: 8 words.
 #ifdef L2HMC_STAMPS
 extern unsigned long long* g_stamp_buf;
+extern int g_stamp_cls;
 #define L2HMC_STAMP(i)                                                                    \
   do {                                                                                    \
     if (p.stamps && threadIdx.x == 0) {                                                   \
