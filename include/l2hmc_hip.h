@@ -108,6 +108,18 @@ typedef struct l2hmc_dense_net {
 size_t l2hmc_dense_pack_bytes(const l2hmc_dense_net* net);
 int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc_stream_t stream);
 
+/* Convolutional front-end of ConvNet3D, channels_last (network/conv_net.py:90-164, 247-262):
+ * per network input Conv3D(F,(3,3,2),same,relu) -> MaxPool3D(2,2,'same') -> Conv3D(2F,(2,2,2),same,relu)
+ * -> MaxPool3D -> flatten to nflat = (T/4)*(X/4)*2F features, which feed the dense trunk above with
+ * Ka = Kb = nflat.  Kernels are passed in the Keras layout [k0][k1][k2][Cin][Cout] unchanged.
+ *   *_a: first input  (conv_v1 / conv_v2)      *_b: second input (conv_x1 / conv_x2)              */
+typedef struct l2hmc_conv3d_front {
+  int32_t F;          /* num_filters (gauge_dynamics.py:130: space_size) */
+  int32_t reserved;
+  const float* w1_a; const float* b1_a; const float* w2_a; const float* b2_a;
+  const float* w1_b; const float* b1_b; const float* w2_b; const float* b2_b;
+} l2hmc_conv3d_front;
+
 /* scratch for one net evaluation on `rows` rows: two [rows][H] activations */
 size_t l2hmc_stq_ws_bytes(int64_t rows, int32_t H);
 
@@ -116,6 +128,13 @@ size_t l2hmc_stq_ws_bytes(int64_t rows, int32_t H);
 int l2hmc_stq_dense(const l2hmc_dense_net* net, const float* a, const float* b, const float* bmask,
                     float t_cos, float t_sin, int64_t rows, float* S, float* T, float* Q,
                     void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+
+/* ConvNet3D.call (network/conv_net.py:247-280) on lattice inputs a, b: [rows][2*T*X]. */
+size_t l2hmc_stq_conv3d_ws_bytes(int64_t rows, int32_t H, int32_t T, int32_t X, int32_t F);
+int l2hmc_stq_conv3d(const l2hmc_conv3d_front* front, const l2hmc_dense_net* net, int32_t T, int32_t X,
+                     const float* a, const float* b, const float* bmask, float t_cos, float t_sin,
+                     int64_t rows, float* S, float* Tr, float* Q, void* ws, size_t ws_bytes,
+                     l2hmc_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Leapfrog sub-updates on materialised S/T/Q (standalone forms).
@@ -148,16 +167,19 @@ int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const flo
  * Lattice integrator: gauge_dynamics.py:412-483 (_forward_lf/_backward_lf),
  * :261-313 (transition_kernel), :195-259 (apply_transition).
  * ------------------------------------------------------------------------ */
-#define L2HMC_PLAN_LAYERED 1
+#define L2HMC_PLAN_LAYERED 1   /* never use the fused whole-trajectory kernel */
+#define L2HMC_PLAN_CONV3D 2    /* nets are ConvNet3D: xfront / vfront are set, nets have Ka = Kb = nflat */
 typedef struct l2hmc_gauge_plan {
   int32_t T, X;            /* lattice extents; D = 2*T*X */
   int32_t num_steps;       /* N_LF */
   int32_t hmc;             /* 1: S=T=Q=0 (gauge_dynamics.py:102-108), nets ignored */
   float eps;
-  int32_t flags;           /* L2HMC_PLAN_LAYERED: never use the fused whole-trajectory kernel */
+  int32_t flags;           /* L2HMC_PLAN_* bits */
   const float* masks;      /* [num_steps][D] 0/1, gauge_dynamics.py:651-661 */
   l2hmc_dense_net xnet;    /* position_fn */
   l2hmc_dense_net vnet;    /* momentum_fn */
+  l2hmc_conv3d_front xfront;   /* conv layers of position_fn (L2HMC_PLAN_CONV3D only) */
+  l2hmc_conv3d_front vfront;   /* conv layers of momentum_fn */
 } l2hmc_gauge_plan;
 
 size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);

@@ -2,7 +2,7 @@
 Dynamics / GaugeDynamics operator surface."""
 from . import _lib  # noqa: F401
 from .lattice import GaugeLattice, u1_plaq_exact, u1_observables  # noqa: F401
-from .network import GenericNet, MLPNet, network  # noqa: F401
+from .network import ConvNet3D, GenericNet, MLPNet, network  # noqa: F401
 from .gauge_dynamics import GaugeDynamics  # noqa: F401
 from .dynamics import Dynamics  # noqa: F401
 from .sampler import propose, tf_accept  # noqa: F401

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
-PLAN_LAYERED = 1
+PLAN_LAYERED, PLAN_CONV3D = 1, 2
 
 
 class DenseNet(C.Structure):
@@ -26,10 +26,16 @@ class DenseNet(C.Structure):
                 ("q_tanh", C.c_int32), ("reserved", C.c_int32), ("packed", c_float_p)]
 
 
+class Conv3DFront(C.Structure):
+    _fields_ = [("F", C.c_int32), ("reserved", C.c_int32),
+                ("w1_a", c_float_p), ("b1_a", c_float_p), ("w2_a", c_float_p), ("b2_a", c_float_p),
+                ("w1_b", c_float_p), ("b1_b", c_float_p), ("w2_b", c_float_p), ("b2_b", c_float_p)]
+
+
 class GaugePlan(C.Structure):
     _fields_ = [("T", C.c_int32), ("X", C.c_int32), ("num_steps", C.c_int32), ("hmc", C.c_int32),
                 ("eps", C.c_float), ("flags", C.c_int32), ("masks", c_float_p),
-                ("xnet", DenseNet), ("vnet", DenseNet)]
+                ("xnet", DenseNet), ("vnet", DenseNet), ("xfront", Conv3DFront), ("vfront", Conv3DFront)]
 
 
 class MogTarget(C.Structure):
@@ -53,6 +59,9 @@ _PROTOS = {
     "l2hmc_kinetic_energy": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "l2hmc_stq_ws_bytes": (_SZ, [_I64, _I32]),
     "l2hmc_stq_dense": (C.c_int, [C.POINTER(DenseNet), _P, _P, _P, _F, _F, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "l2hmc_stq_conv3d_ws_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I32]),
+    "l2hmc_stq_conv3d": (C.c_int, [C.POINTER(Conv3DFront), C.POINTER(DenseNet), _I32, _I32, _P, _P, _P, _F, _F,
+                                   _I64, _P, _P, _P, _P, _SZ, _P]),
     "l2hmc_dense_pack_bytes": (_SZ, [C.POINTER(DenseNet)]),
     "l2hmc_dense_pack": (C.c_int, [C.POINTER(DenseNet), _P, _P]),
     "l2hmc_lf_update_v": (C.c_int, [_P, _P, _P, _P, _P, _F, _I32, _I64, _I32, _P, _P, _P]),

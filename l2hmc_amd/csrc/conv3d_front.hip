@@ -1,0 +1,159 @@
+// Convolutional front-end of ConvNet3D (channels_last) for gfx950:
+//   l2hmc/network/conv_net.py:247-262  reshape_5D -> Conv3D(F,(3,3,2),same,relu) -> MaxPool3D(2,s2,same)
+//                                      -> Conv3D(2F,(2,2,2),same,relu) -> MaxPool3D(2,s2,same) -> flatten
+// applied to each of the two network inputs with its own filters (conv_v*, conv_x*).
+// Keras/TF conventions restated (they are not in the reference tree): zero padding, 'same' pads
+// floor((k-1)/2) before and the rest after, pooling windows are clipped at the border, flatten is
+// row-major over (h, w, depth, channel).  On the link-direction axis (size 2) the (.,.,2) kernel sees
+// one real and one padded tap for output depth 1, and after the first pool that axis has size 1, so
+// only the dd=0 slice of the second kernel ever touches data.
+//
+// One launch handles both inputs (blockIdx.y).  A chain is a few hundred floats: it is staged in LDS
+// with a zero halo, conv1+relu+pool1 and conv2+relu+pool2 run out of LDS (max and relu commute), and
+// the flattened features go straight into the k-contiguous layout the dense trunk's first GEMM reads.
+// This stage is <20 % of the network's FLOPs and VALU-bound; filters are read with
+// the channel index on the lane (conflict-free), inputs as LDS broadcasts.
+#include "stq_dense.h"
+
+namespace l2hmc {
+
+constexpr int kConvThreads = 256;
+
+__global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArgs p) {
+  extern __shared__ float lds[];
+  const int which = blockIdx.y;                   // 0: first input, 1: second input
+  const int T = p.T, X = p.X, F = p.F, F2 = 2 * p.F;
+  const int D = 2 * T * X;
+  const int TP = T + 2, XP = X + 2;               // conv1 halo (pad 1 / 1)
+  const int T2 = T / 2, X2 = X / 2, T2P = T2 + 1, X2P = X2 + 1;   // conv2 pad (0 / 1)
+  const int T4 = T / 4, X4 = X / 4;
+  const int cpw = p.cpw;
+  float* w1 = lds;                                 // [3][3][2][F]
+  float* b1 = w1 + 18 * F;
+  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice)
+  float* b2 = w2 + 4 * F * F2;
+  float* xin = b2 + F2;                            // [cpw][TP][XP][2]
+  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][F]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * cpw;
+  const int nrow = (int)min((int64_t)cpw, p.rows - row0);
+
+  const float* gw1 = p.w1[which];
+  const float* gw2 = p.w2[which];
+  for (int i = tid; i < 18 * F; i += kConvThreads) w1[i] = gw1[i];
+  for (int i = tid; i < F; i += kConvThreads) b1[i] = p.b1[which][i];
+  for (int i = tid; i < 4 * F * F2; i += kConvThreads) {
+    // Keras kernel [di][dj][dd][c][g]: keep dd = 0
+    const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
+    w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
+  }
+  for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
+  for (int i = tid; i < cpw * TP * XP * 2; i += kConvThreads) xin[i] = 0.f;
+  for (int i = tid; i < cpw * T2P * X2P * F; i += kConvThreads) p1[i] = 0.f;
+  __syncthreads();
+  const float* in = p.in[which];
+  const bool masked = which == 1 && p.cmask_f != nullptr;
+  for (int i = tid; i < nrow * D; i += kConvThreads) {
+    const int c = i / D, e = i - c * D;
+    float v = in[(row0 + c) * D + e];
+    if (masked) {
+      const int d = p.dir ? p.dir[row0 + c] : 0;
+      v *= (d ? p.cmask_b : p.cmask_f)[e];
+    }
+    const int site = e >> 1, mu = e & 1;
+    const int ii = site / X, jj = site - ii * X;
+    xin[((c * TP + ii + 1) * XP + jj + 1) * 2 + mu] = v;
+  }
+  __syncthreads();
+
+  // ---- conv1 (3,3,2) + relu + pool (2,2,2): pooled output (c, I, J, f), f on the lane
+  const int n1 = nrow * T2 * X2 * F;
+  for (int idx = tid; idx < n1; idx += kConvThreads) {
+    const int f = idx % F;
+    int r = idx / F;
+    const int J = r % X2;
+    r /= X2;
+    const int I = r % T2, c = r / T2;
+    const float bias = b1[f];
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int i = 2 * I + a, j = 2 * J + bb;             // un-haloed output site
+        float v0 = bias, v1 = bias;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+#pragma unroll
+          for (int dj = 0; dj < 3; ++dj) {
+            const float* px = xin + ((c * TP + i + di) * XP + j + dj) * 2;   // halo shifts by +1, tap by -1
+            const float x0 = px[0], x1 = px[1];
+            const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
+            v0 += x0 * k0 + x1 * k1;       // output depth 0 sees (mu=0, mu=1)
+            v1 += x1 * k0;                 // output depth 1 sees (mu=1, pad)
+          }
+        }
+        m = fmaxf(m, fmaxf(v0, v1));
+      }
+    }
+    p1[((c * T2P + I) * X2P + J) * F + f] = fmaxf(m, 0.f);
+  }
+  __syncthreads();
+
+  // ---- conv2 (2,2,[2]) + relu + pool (2,2,[1]): output (c, I2, J2, g), g on the lane
+  const int n2 = nrow * T4 * X4 * F2;
+  float* out = p.out[which];
+  for (int idx = tid; idx < n2; idx += kConvThreads) {
+    const int g = idx % F2;
+    int r = idx / F2;
+    const int J2 = r % X4;
+    r /= X4;
+    const int I2 = r % T4, c = r / T4;
+    const float bias = b2[g];
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int i = 2 * I2 + a, j = 2 * J2 + bb;
+        float v = bias;
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+#pragma unroll
+          for (int dj = 0; dj < 2; ++dj) {
+            const float* pp = p1 + ((c * T2P + i + di) * X2P + j + dj) * F;   // zero halo beyond the edge
+            const float* kk = w2 + ((di * 2 + dj) * F) * F2 + g;
+            for (int ch = 0; ch < F; ++ch) v += pp[ch] * kk[ch * F2];
+          }
+        }
+        m = fmaxf(m, v);
+      }
+    }
+    out[(row0 + c) * p.ldo + (I2 * X4 + J2) * F2 + g] = fmaxf(m, 0.f);
+  }
+}
+
+int conv3d_nflat(int T, int X, int F) { return (T / 4) * (X / 4) * 2 * F; }
+
+int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
+  L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0, "conv3d front-end: T=%d X=%d must be multiples of 4", a.T,
+                a.X);
+  const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
+  a.cpw = per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
+  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
+                                      (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
+                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
+  L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
+  hipLaunchKernelGGL(conv3d_front_kernel, grid, dim3(kConvThreads), lds, stream, a);
+  L2HMC_CHECK_LAUNCH("conv3d_front");
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc

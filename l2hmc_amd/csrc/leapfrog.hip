@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void accept_selected_kernel(const float* __res
 // host orchestration
 // =====================================================================
 struct GaugeWs {
-  float* h1; float* h2; float* g; float* ld_part; float* mask_inv;
+  float* h1; float* h2; float* g; float* ld_part; float* mask_inv; float* fa; float* fb;
   float* act0; float* kin0; float* act1; float* kin1;
   size_t bytes;
 };
 
 static bool use_fused(const l2hmc_gauge_plan* p) {
-  return !(p->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(p);
+  return !(p->flags & (L2HMC_PLAN_LAYERED | L2HMC_PLAN_CONV3D)) && fused_plan_supported(p);
 }
 static int gauge_hmax(const l2hmc_gauge_plan* p) { return p->hmc ? 0 : hmax(p->xnet.H, p->vnet.H); }
 static int gauge_ncb(const l2hmc_gauge_plan* p) { return (int)ceil_div(2 * p->T * p->X, 32); }
@@ -197,6 +197,9 @@ static GaugeWs carve_gauge_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   w.g = take((size_t)rows * D);
   w.ld_part = take((size_t)rows * gauge_ncb(p));
   w.mask_inv = take((size_t)p->num_steps * D);
+  const size_t nflat = (p->flags & L2HMC_PLAN_CONV3D) ? conv3d_nflat(p->T, p->X, p->xfront.F) : 0;
+  w.fa = take((size_t)rows * nflat);
+  w.fb = take((size_t)rows * nflat);
   w.act0 = take(rows);
   w.kin0 = take(rows);
   w.act1 = take(rows);
@@ -217,8 +220,19 @@ static int check_plan(const l2hmc_gauge_plan* p) {
       L2HMC_REQUIRE(dense_net_supported(n),
                     "plan: net widths (Ka=%d, Kb=%d, H=%d) must be positive multiples of 32", n->Ka, n->Kb,
                     n->H);
-      L2HMC_REQUIRE(n->Ka == D && n->Kb == D, "plan: generic net expects Ka=Kb=x_dim (got %d, %d)", n->Ka,
-                    n->Kb);
+      if (p->flags & L2HMC_PLAN_CONV3D) {
+        const l2hmc_conv3d_front* f = (n == &p->xnet) ? &p->xfront : &p->vfront;
+        L2HMC_REQUIRE(f->F > 0 && p->T % 4 == 0 && p->X % 4 == 0, "plan: conv3D needs T, X multiples of 4 and F > 0");
+        L2HMC_REQUIRE(p->xfront.F == p->vfront.F, "plan: both nets must use the same num_filters");
+        const int nf = conv3d_nflat(p->T, p->X, f->F);
+        L2HMC_REQUIRE(n->Ka == nf && n->Kb == nf, "plan: conv3D trunk expects Ka=Kb=%d (got %d, %d)", nf, n->Ka,
+                      n->Kb);
+        L2HMC_REQUIRE(f->w1_a && f->b1_a && f->w2_a && f->b2_a && f->w1_b && f->b1_b && f->w2_b && f->b2_b,
+                      "plan: conv front-end has NULL weight pointer");
+      } else {
+        L2HMC_REQUIRE(n->Ka == D && n->Kb == D, "plan: generic net expects Ka=Kb=x_dim (got %d, %d)", n->Ka,
+                      n->Kb);
+      }
       L2HMC_REQUIRE(n->w1_t && n->wt && n->b1 && n->wh_t && n->bh && n->whd_t && n->bhd && n->coeff_s &&
                         n->coeff_q,
                     "plan: net has NULL weight pointer");
@@ -229,10 +243,23 @@ static int check_plan(const l2hmc_gauge_plan* p) {
 }
 
 // one S/T/Q evaluation of `net` on (a, b*mask), fused with the v or x update
-static int net_update(const l2hmc_dense_net* net, const float* a, const float* b, const float* cm_f,
-                      const float* cm_b, const int* dir, const float tcs[4], int64_t rows, int mode,
-                      float* x, float* v, const float* g, const float* keep_f, const float* keep_b,
-                      float eps, const GaugeWs& w, int ncb, hipStream_t stream) {
+static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, const float* a,
+                      const float* b, const float* cm_f, const float* cm_b, const int* dir,
+                      const float tcs[4], int64_t rows, int mode, float* x, float* v, const float* g,
+                      const float* keep_f, const float* keep_b, float eps, const GaugeWs& w, int ncb,
+                      hipStream_t stream) {
+  if (plan->flags & L2HMC_PLAN_CONV3D) {
+    // conv_net.py:251-262: both inputs through their conv stacks, then the dense trunk on the features
+    const l2hmc_conv3d_front* f = (net == &plan->xnet) ? &plan->xfront : &plan->vfront;
+    ConvFrontArgs c{};
+    c.T = plan->T; c.X = plan->X; c.F = f->F;
+    c.in[0] = a; c.in[1] = b; c.cmask_f = cm_f; c.cmask_b = cm_b; c.dir = dir;
+    c.w1[0] = f->w1_a; c.b1[0] = f->b1_a; c.w2[0] = f->w2_a; c.b2[0] = f->b2_a;
+    c.w1[1] = f->w1_b; c.b1[1] = f->b1_b; c.w2[1] = f->w2_b; c.b2[1] = f->b2_b;
+    c.out[0] = w.fa; c.out[1] = w.fb; c.ldo = net->Ka; c.rows = rows;
+    if (int e = launch_conv3d_front(c, stream)) return e;
+    a = w.fa; b = w.fb; cm_f = cm_b = nullptr;
+  }
   GemmReluArgs l1{};
   l1.A1 = a; l1.lda1 = net->Ka; l1.K1 = net->Ka;
   l1.A2 = b; l1.lda2 = net->Kb;
@@ -292,7 +319,7 @@ static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float*
                              nullptr, nullptr, p->eps, dir, 0, rows, D, x, nullptr, 0);
           L2HMC_CHECK_LAUNCH("lf_update_x");
         } else {
-          if (int e = net_update(&p->xnet, v, x, kf, kb, dir, tcs, rows, /*mode x*/ 2, x, v, nullptr, kf, kb,
+          if (int e = net_update(p, &p->xnet, v, x, kf, kb, dir, tcs, rows, /*mode x*/ 2, x, v, nullptr, kf, kb,
                                  p->eps, w, ncb, stream))
             return e;
         }
@@ -306,7 +333,7 @@ static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float*
                          nullptr, p->eps, dir, 0, rows, D, v, nullptr, 0);
       L2HMC_CHECK_LAUNCH("lf_update_v");
     } else {
-      if (int e = net_update(&p->vnet, x, w.g, nullptr, nullptr, dir, tcs, rows, /*mode v*/ 1, x, v, w.g,
+      if (int e = net_update(p, &p->vnet, x, w.g, nullptr, nullptr, dir, tcs, rows, /*mode v*/ 1, x, v, w.g,
                              nullptr, nullptr, p->eps, w, ncb, stream))
         return e;
     }
@@ -459,6 +486,40 @@ extern "C" int l2hmc_stq_dense(const l2hmc_dense_net* net, const float* a, const
   h.q_tanh = net->q_tanh; h.D = net->D; h.rows = rows; h.mode = 0;
   h.S = S; h.T = T; h.Q = Q;
   return launch_heads(h, s);
+}
+
+extern "C" size_t l2hmc_stq_conv3d_ws_bytes(int64_t rows, int32_t H, int32_t T, int32_t X, int32_t F) {
+  return l2hmc_stq_ws_bytes(rows, H) + 2 * align_up(sizeof(float) * (size_t)rows * conv3d_nflat(T, X, F), 256);
+}
+
+extern "C" int l2hmc_stq_conv3d(const l2hmc_conv3d_front* front, const l2hmc_dense_net* net, int32_t T, int32_t X,
+                                const float* a, const float* b, const float* bmask, float t_cos, float t_sin,
+                                int64_t rows, float* S, float* Tr, float* Q, void* ws, size_t ws_bytes,
+                                l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(front && net && rows >= 0 && T > 0 && X > 0, "stq_conv3d: bad arguments");
+  if (rows == 0) return L2HMC_OK;
+  const int nf = conv3d_nflat(T, X, front->F);
+  L2HMC_REQUIRE(net->Ka == nf && net->Kb == nf, "stq_conv3d: trunk expects Ka=Kb=%d (got %d, %d)", nf, net->Ka,
+                net->Kb);
+  L2HMC_REQUIRE(a && b && S && Tr && Q && ws, "stq_conv3d: NULL pointer");
+  const size_t need = l2hmc_stq_conv3d_ws_bytes(rows, net->H, T, X, front->F);
+  if (ws_bytes < need) {
+    set_error("stq_conv3d: workspace %zu < %zu bytes", ws_bytes, need);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  const size_t fbytes = align_up(sizeof(float) * (size_t)rows * nf, 256);
+  float* fa = reinterpret_cast<float*>(base);
+  float* fb = reinterpret_cast<float*>(base + fbytes);
+  ConvFrontArgs c{};
+  c.T = T; c.X = X; c.F = front->F;
+  c.in[0] = a; c.in[1] = b; c.cmask_f = bmask; c.cmask_b = bmask;
+  c.w1[0] = front->w1_a; c.b1[0] = front->b1_a; c.w2[0] = front->w2_a; c.b2[0] = front->b2_a;
+  c.w1[1] = front->w1_b; c.b1[1] = front->b1_b; c.w2[1] = front->w2_b; c.b2[1] = front->b2_b;
+  c.out[0] = fa; c.out[1] = fb; c.ldo = nf; c.rows = rows;
+  if (int e = launch_conv3d_front(c, (hipStream_t)stream)) return e;
+  return l2hmc_stq_dense(net, fa, fb, nullptr, t_cos, t_sin, rows, S, Tr, Q, base + 2 * fbytes,
+                         ws_bytes - 2 * fbytes, stream);
 }
 
 // ---------------------------------------------------------------------------

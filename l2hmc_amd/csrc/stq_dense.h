@@ -70,6 +70,21 @@ extern int g_stamp_cls;
 #define L2HMC_STAMP_REAL(i) do {} while (0)
 #endif
 
+// conv front-end of ConvNet3D, both network inputs in one launch (index 0: first input, 1: second)
+struct ConvFrontArgs {
+  int T, X, F;
+  const float* in[2];                    // [rows][2*T*X]
+  const float* cmask_f; const float* cmask_b;   // optional [D] multiplier on the SECOND input, per direction
+  const int* dir;                        // [rows] or NULL
+  const float* w1[2]; const float* b1[2];   // Conv3D kernels [3][3][2][1][F], biases [F]
+  const float* w2[2]; const float* b2[2];   // Conv3D kernels [2][2][2][F][2F], biases [2F]
+  float* out[2]; int ldo;                // [rows][nflat] flattened features
+  int64_t rows;
+  int cpw;                               // chains per workgroup (set by the launcher)
+};
+int conv3d_nflat(int T, int X, int F);
+int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream);
+
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
 int launch_heads(HeadsArgs& a, hipStream_t stream);
 int dense_net_supported(const l2hmc_dense_net* n);

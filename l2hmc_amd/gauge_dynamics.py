@@ -16,7 +16,7 @@ import numpy.random as npr
 import torch
 
 from . import _lib
-from .network import GenericNet
+from .network import ConvNet3D, GenericNet
 
 
 class GaugeDynamics:
@@ -48,10 +48,12 @@ class GaugeDynamics:
             self.momentum_fn = lambda inp: [torch.zeros_like(inp[0]) for _ in range(3)]
         elif self.network_arch == 'generic':
             self._build_generic_nets()
-        elif self.network_arch in ('conv3D', 'conv2D'):
+        elif self.network_arch == 'conv3D':
+            self._build_conv_nets_3D()
+        elif self.network_arch == 'conv2D':
             raise NotImplementedError(
-                f"network_arch={self.network_arch!r}: the conv front-end is not built yet on the HIP path "
-                "(DESIGN.md, scope table)")
+                "network_arch='conv2D' is out of scope (SURVEY.md section 2: not named by any benchmark "
+                "config, and its 4-D outputs break the reference's own reduce_sum(axis=1))")
         else:                            # :117-119
             raise AttributeError("`self._network_arch` must be one of `'conv3D', 'conv2D', 'generic'.`")
         self._ws = _lib.Workspace()
@@ -67,6 +69,25 @@ class GaugeDynamics:
         kwargs['factor'] = 1.
         kwargs['name_scope'] = 'momentum'
         self.momentum_fn = GenericNet(model_name='VNet', device=self._device, **kwargs)
+
+    def _build_conv_nets_3D(self):
+        """:121-143."""
+        kwargs = {
+            '_input_shape': (self.batch_size, *self.lattice.links.shape),
+            'links_shape': self.lattice.links.shape,
+            'x_dim': self.lattice.num_links,
+            'factor': 2.,
+            'spatial_size': self.lattice.space_size,
+            'num_hidden': 2 * self.lattice.num_links,
+            'num_filters': int(self.lattice.space_size),
+            'filter_sizes': [(3, 3, 2), (2, 2, 2)],
+            'name_scope': 'position',
+            'data_format': self.data_format,
+        }
+        self.position_fn = ConvNet3D(model_name='XNet', device=self._device, **kwargs)
+        kwargs['name_scope'] = 'momentum'
+        kwargs['factor'] = 1.
+        self.momentum_fn = ConvNet3D(model_name='VNet', device=self._device, **kwargs)
 
     def _construct_time(self):
         """:611-619."""
@@ -113,6 +134,10 @@ class GaugeDynamics:
         if not self.hmc:
             p.xnet = self.position_fn.pack()
             p.vnet = self.momentum_fn.pack()
+            if self.network_arch == 'conv3D':
+                p.flags |= _lib.PLAN_CONV3D
+                p.xfront = self.position_fn.pack_front()
+                p.vfront = self.momentum_fn.pack_front()
         return p
 
     def _x(self, a):

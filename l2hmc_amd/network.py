@@ -173,6 +173,130 @@ class GenericNet(_DenseSTQ):
         self._ws = _lib.Workspace()
 
 
+class Conv3D:
+    """tf.keras.layers.Conv3D stand-in (parameters only): `kernel` [k0, k1, k2, Cin, Cout] with the
+    Keras default glorot_uniform init, zero `bias` (conv_net.py:90-99 passes no initialiser)."""
+
+    def __init__(self, kernel_size, cin, filters, name=None, rng=None, device=None):
+        rng = rng if rng is not None else np.random
+        shape = tuple(kernel_size) + (cin, filters)
+        receptive = int(np.prod(kernel_size))
+        lim = np.sqrt(6.0 / (cin * receptive + filters * receptive))
+        self.name = name
+        self.kernel = torch.from_numpy(rng.uniform(-lim, lim, shape).astype(np.float32)).to(device)
+        self.bias = torch.zeros(filters, dtype=torch.float32, device=device)
+
+    @property
+    def variables(self):
+        return [self.kernel, self.bias]
+
+
+class ConvNet3D(_DenseSTQ):
+    """conv_net.py:57-310, channels_last.  kwargs as the reference passes them
+    (gauge_dynamics.py:123-134): _input_shape, links_shape, x_dim, factor, spatial_size, num_hidden,
+    num_filters, filter_sizes, name_scope, data_format."""
+    q_tanh = 0
+    _layer_names = GenericNet._layer_names
+    _coeff_names = GenericNet._coeff_names
+    _conv_names = ("conv_x1", "conv_v1", "conv_x2", "conv_v2")
+
+    def __init__(self, model_name, rng=None, device=None, **kwargs):
+        self.name = model_name
+        self.data_format = 'channels_last'
+        self.filter_sizes = [(3, 3, 2), (2, 2, 2)]
+        for key, val in kwargs.items():
+            setattr(self, key, val)
+        if self.data_format != 'channels_last':
+            raise NotImplementedError("only data_format='channels_last' (the CPU/TF reference layout) is built; "
+                                      "channels_first reinterprets the link buffer (SURVEY.md 8a)")
+        if [tuple(f) for f in self.filter_sizes] != [(3, 3, 2), (2, 2, 2)]:
+            raise NotImplementedError("the conv kernels are written for filter_sizes [(3,3,2),(2,2,2)]")
+        self._device = device or torch.device("cuda", torch.cuda.current_device())
+        dev, D, H, F = self._device, int(self.x_dim), int(self.num_hidden), int(self.num_filters)
+        T, X = int(self.links_shape[0]), int(self.links_shape[1])
+        if T % 4 or X % 4:
+            raise ValueError("ConvNet3D on the HIP path needs lattice extents that are multiples of 4")
+        self.nflat = (T // 4) * (X // 4) * 2 * F
+        self.coeff_scale = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        self.coeff_transformation = torch.zeros(1, D, dtype=torch.float32, device=dev)
+        # creation order of conv_net.py:90-164
+        self.conv_x1 = Conv3D((3, 3, 2), 1, F, 'conv_x1', rng, dev)
+        self.conv_v1 = Conv3D((3, 3, 2), 1, F, 'conv_v1', rng, dev)
+        self.conv_x2 = Conv3D((2, 2, 2), F, 2 * F, 'conv_x2', rng, dev)
+        self.conv_v2 = Conv3D((2, 2, 2), F, 2 * F, 'conv_v2', rng, dev)
+        self.x_layer = Dense(self.nflat, H, self.factor / 3., 'x_layer', rng, dev)
+        self.v_layer = Dense(self.nflat, H, 1. / 3., 'v_layer', rng, dev)
+        self.t_layer = Dense(2, H, 1. / 3., 't_layer', rng, dev)
+        self.h_layer = Dense(H, H, 1., 'h_layer', rng, dev)
+        self.scale_layer = Dense(H, D, 0.001, 'scale_layer', rng, dev)
+        self.translation_layer = Dense(H, D, 0.001, 'translation_layer', rng, dev)
+        self.transformation_layer = Dense(H, D, 0.001, 'transformation_layer', rng, dev)
+        self._packed = None
+        self._front = None
+        self._ws = _lib.Workspace()
+
+    @property
+    def variables(self):
+        out = [self.coeff_scale, self.coeff_transformation]
+        for n in self._conv_names:
+            out.extend(getattr(self, n).variables)
+        for layer in self._layers():
+            out.extend(layer.variables)
+        return out
+
+    trainable_variables = variables
+
+    def state_dict(self):
+        d = super().state_dict()
+        for n in self._conv_names:
+            d[n + "/W"] = getattr(self, n).kernel
+            d[n + "/b"] = getattr(self, n).bias
+        return d
+
+    def load_state(self, state):
+        super().load_state(state)
+        for n in self._conv_names:
+            layer = getattr(self, n)
+            W = _lib.as_dev(state[n + "/W"], self._device)
+            b = _lib.as_dev(state[n + "/b"], self._device)
+            if W.shape != layer.kernel.shape or b.shape != layer.bias.shape:
+                raise ValueError(f"{n}: shape {tuple(W.shape)} != {tuple(layer.kernel.shape)}")
+            layer.kernel, layer.bias = W, b
+        self._front = None
+
+    def pack_front(self):
+        """struct l2hmc_conv3d_front: *_a = first input (conv_v*), *_b = second input (conv_x*)."""
+        if self._front is None:
+            t = {k: getattr(self, k) for k in self._conv_names}
+            ptr = lambda x, n: _lib.dev_ptr(x.contiguous(), name=n)   # noqa: E731
+            self._front = _lib.Conv3DFront(
+                F=int(self.num_filters), reserved=0,
+                w1_a=ptr(t["conv_v1"].kernel, "conv_v1"), b1_a=ptr(t["conv_v1"].bias, "conv_v1/b"),
+                w2_a=ptr(t["conv_v2"].kernel, "conv_v2"), b2_a=ptr(t["conv_v2"].bias, "conv_v2/b"),
+                w1_b=ptr(t["conv_x1"].kernel, "conv_x1"), b1_b=ptr(t["conv_x1"].bias, "conv_x1/b"),
+                w2_b=ptr(t["conv_x2"].kernel, "conv_x2"), b2_b=ptr(t["conv_x2"].bias, "conv_x2/b"))
+        return self._front
+
+    def __call__(self, inputs):
+        """conv_net.py:247-280: (scale, translation, transformation) = net([v, x, t])."""
+        a, b, t = inputs[0], inputs[1], inputs[2]
+        a = _lib.as_dev(a, self._device).reshape(a.shape[0], -1)
+        b = _lib.as_dev(b, self._device).reshape(b.shape[0], -1)
+        t = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 2)
+        st, fr = self.pack(), self.pack_front()
+        T, X = int(self.links_shape[0]), int(self.links_shape[1])
+        rows = a.shape[0]
+        S, Tr, Q = (torch.empty(rows, st.D, dtype=torch.float32, device=a.device) for _ in range(3))
+        L = _lib.lib()
+        ws, nb = self._ws.get(L.l2hmc_stq_conv3d_ws_bytes(rows, st.H, T, X, fr.F), a.device)
+        _lib.check(L.l2hmc_stq_conv3d(C.byref(fr), C.byref(st), T, X, _lib.dev_ptr(a, name="a"),
+                                      _lib.dev_ptr(b, name="b"), None, float(t[0, 0]), float(t[0, 1]), rows,
+                                      S.data_ptr(), Tr.data_ptr(), Q.data_ptr(), ws, nb, _lib.stream_ptr()))
+        return S, Tr, Q
+
+    call = __call__
+
+
 class MLPNet(_DenseSTQ):
     """utils/network.py:89-114: what `network(x_dim, scope, factor, num_nodes)` returns.
     Callable on [a, b, t, aux]; aux is ignored (the `lambda _: 0.` slot)."""

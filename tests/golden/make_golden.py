@@ -39,13 +39,16 @@ def u1_case():
     np.savez_compressed(os.path.join(HERE, "u1_obs.npz"), **out)
 
 
-def gauge_case(name, T, X, N, eps, beta, B, regime, store_weights):
+def gauge_case(name, T, X, N, eps, beta, B, regime, store_weights, arch='generic'):
     D = 2 * T * X
-    xp, vp = H.gauge_weights(T, X, seed=106, regime=regime)
-    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    if arch == 'conv3D':
+        xp, vp = H.conv_weights(T, X, seed=106, regime=regime)
+    else:
+        xp, vp = H.gauge_weights(T, X, seed=106, regime=regime)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp, arch=arch)
     x, v0f, v0b, coin, u = H.gauge_inputs(B, D, seed=103)
     out = dict(T=T, X=X, num_steps=N, eps=eps, beta=beta, masks=orc.mask, x=x, v0f=v0f, v0b=v0b, coin=coin, u=u,
-               regime=regime, xnet_checksum=wsum(xp), vnet_checksum=wsum(vp))
+               regime=regime, arch=arch, xnet_checksum=wsum(xp), vnet_checksum=wsum(vp))
     if store_weights:
         for k, v in xp.items():
             out["xnet/" + k] = v.astype(np.float32)
@@ -53,7 +56,7 @@ def gauge_case(name, T, X, N, eps, beta, B, regime, store_weights):
             out["vnet/" + k] = v.astype(np.float32)
         xp = {k: v.astype(np.float32).astype(np.float64) for k, v in xp.items()}
         vp = {k: v.astype(np.float32).astype(np.float64) for k, v in vp.items()}
-        orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+        orc = H.gauge_oracle(T, X, N, eps, xp, vp, arch=arch)
     for tag, v0, fwd in (("f", v0f, True), ("b", v0b, False)):
         trace = []
         xN, vN, p, sld = orc.transition_kernel(x, beta, v0, forward=fwd, trace=trace)
@@ -100,6 +103,7 @@ if __name__ == "__main__":
     gauge_case("gauge_L4_stress", 4, 4, 3, 0.2, 2.5, 6, "stress", store_weights=True)
     gauge_case("gauge_L8_cfg3_init", 8, 8, 10, 0.25, 2.0, 4, "init", store_weights=False)
     gauge_case("gauge_L8_cfg3_mild", 8, 8, 10, 0.25, 2.0, 4, "mild", store_weights=False)
+    gauge_case("gauge_L8_conv3d_mild", 8, 8, 5, 0.25, 2.0, 4, "mild", store_weights=False, arch='conv3D')
     small_case("mog_cfg2", H.mog_target_oracle(), 50, 10, 0.1, 32, 102)
     small_case("scg_cfg1", H.scg_target_oracle(), 10, 5, 0.1, 32, 101)
     for f in sorted(os.listdir(HERE)):

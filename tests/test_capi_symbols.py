@@ -25,11 +25,23 @@ def test_library_exports_every_declared_symbol(L):
     assert L.l2hmc_abi_version() == 1
 
 
-def test_struct_layouts_match_header_sizes():
-    # pointers are 8 bytes; a mismatch here would silently corrupt every call
-    assert C.sizeof(_lib.DenseNet) == 4 * 4 + 9 * 8 + 2 * 4 + 8
-    assert C.sizeof(_lib.GaugePlan) == 6 * 4 + 8 + 2 * C.sizeof(_lib.DenseNet)
-    assert C.sizeof(_lib.MogTarget) == 4 * 4 + 3 * 8
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """sizeof/offsetof as gcc sees include/l2hmc_hip.h vs the ctypes mirrors: a mismatch would corrupt every call."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "l2hmc_hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(l2hmc_dense_net),'
+        ' sizeof(l2hmc_conv3d_front), sizeof(l2hmc_gauge_plan), sizeof(l2hmc_mog_target), sizeof(l2hmc_small_plan),'
+        ' offsetof(l2hmc_dense_net, packed), offsetof(l2hmc_gauge_plan, masks), offsetof(l2hmc_gauge_plan, vfront),'
+        ' offsetof(l2hmc_small_plan, target)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(_lib.DenseNet), C.sizeof(_lib.Conv3DFront), C.sizeof(_lib.GaugePlan), C.sizeof(_lib.MogTarget),
+            C.sizeof(_lib.SmallPlan), _lib.DenseNet.packed.offset, _lib.GaugePlan.masks.offset,
+            _lib.GaugePlan.vfront.offset, _lib.SmallPlan.target.offset]
+    assert got == want
 
 
 def test_empty_inputs_are_ok_without_a_gpu(L):

@@ -280,6 +280,8 @@ def test_constructor_surface_and_errors(la):
     out = d(torch.as_tensor(lat.samples.reshape(4, -1)), 2.0)
     assert [tuple(o.shape) for o in out] == [(4, 128), (4, 128), (4,), (4, 128)]
     assert torch.all((out[2] >= 0) & (out[2] <= 1))
+    with pytest.raises(NotImplementedError):  # conv2D is out of scope
+        la.GaugeDynamics(lat, fn, eps=0.3, hmc=False, network_arch='conv2D', num_steps=3, eps_trainable=True)
     with pytest.raises(AttributeError):      # gauge_dynamics.py:117-119
         la.GaugeDynamics(lat, fn, eps=0.3, hmc=False, network_arch='bogus', num_steps=3, eps_trainable=True)
     with pytest.raises(NotImplementedError):
@@ -288,19 +290,68 @@ def test_constructor_surface_and_errors(la):
     d.position_fn.load_weights("/tmp/_xnet_weights")
 
 
+# ----------------------------------------------------------------- ConvNet3D (network/conv_net.py)
+@pytest.mark.parametrize("L,rows,regime", [(8, 37, "stress"), (8, 3, "init"), (16, 9, "stress")])
+def test_stq_conv3d_matches_oracle(la, L, rows, regime):
+    D = 2 * L * L
+    xp, _ = H.conv_weights(L, L, regime=regime)
+    net = la.ConvNet3D('XNet', _input_shape=(rows, L, L, 2), links_shape=(L, L, 2), x_dim=D, factor=2.,
+                       spatial_size=L, num_hidden=2 * D, num_filters=L, filter_sizes=[(3, 3, 2), (2, 2, 2)],
+                       name_scope='position', data_format='channels_last')
+    net.load_state(xp)
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal((rows, D)), rng.uniform(0, 6.3, (rows, D))
+    t = np.array([[np.cos(0.7), np.sin(0.7)]])
+    S, Tr, Q = net([a, b, t])
+    p32 = {k: v.astype(np.float32).astype(np.float64) for k, v in xp.items()}
+    f32 = lambda z: z.astype(np.float32).astype(np.float64)   # noqa: E731
+    So, To, Qo = onets.conv3d_net(p32, [f32(a), f32(b), np.tile(f32(t), (rows, 1))], (L, L, 2))
+    assert H.relerr(np_(S), So) < TOL_OP and H.relerr(np_(Tr), To) < TOL_OP and H.relerr(np_(Q), Qo) < TOL_OP
+    assert np.abs(To).max() > 1e-4
+
+
+@pytest.mark.parametrize("L,N,B,regime", [(8, 5, 37, "mild"), (8, 3, 16, "stress"), (16, 2, 6, "init")])
+def test_conv3d_dynamics_matches_oracle(la, L, N, B, regime):
+    eps, beta, D = 0.2, 2.0, 2 * L * L
+    xp, vp = H.conv_weights(L, L, regime=regime)
+    orc = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D')
+    orc32 = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D', dtype=np.float32)
+    dyn = H.gauge_hip(L, L, N, eps, xp, vp, orc.mask, B, arch='conv3D')
+    assert dyn.position_fn.num_hidden == 2 * D and dyn.position_fn.num_filters == L     # gauge_dynamics.py:129-130
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, D)
+    for step in (0, N - 1):
+        for fn, ofn in ((dyn._forward_lf, orc._forward_lf), (dyn._backward_lf, orc._backward_lf)):
+            x1, v1, ld = fn(x, v0f, beta, step)
+            ox, ov, old = ofn(x, v0f, beta, step)
+            assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP
+            assert H.relerr(np_(ld), old) < TOL_OP
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    f32 = orc32.apply_transition(x.astype(np.float32), beta, v0f.astype(np.float32), v0b.astype(np.float32), coin,
+                                 u.astype(np.float32))
+    for both in (True, False):
+        dyn.both_directions = both
+        got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
+        assert_fp32_equivalent(got[0], want[0], f32[0], "x_prop")
+        assert_fp32_equivalent(got[1], want[1], f32[1], "v_prop")
+        assert np.abs(got[2] - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+
+
 # ----------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("name,fused", [("gauge_L4_stress", True), ("gauge_L8_cfg3_init", True),
-                                        ("gauge_L8_cfg3_init", False), ("gauge_L8_cfg3_mild", True)])
+                                        ("gauge_L8_cfg3_init", False), ("gauge_L8_cfg3_mild", True),
+                                        ("gauge_L8_conv3d_mild", True)])
 def test_golden_gauge(la, name, fused):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     T, X, N = int(g["T"]), int(g["X"]), int(g["num_steps"])
+    arch = str(g["arch"]) if "arch" in g.files else "generic"
     if "xnet/h_layer/W" in g.files:
         xp = {k[5:]: g[k] for k in g.files if k.startswith("xnet/")}
         vp = {k[5:]: g[k] for k in g.files if k.startswith("vnet/")}
     else:
-        xp, vp = H.gauge_weights(T, X, seed=106, regime=str(g["regime"]))
+        mk = H.conv_weights if arch == "conv3D" else H.gauge_weights
+        xp, vp = mk(T, X, seed=106, regime=str(g["regime"]))
     B = g["x"].shape[0]
-    dyn = H.gauge_hip(T, X, N, float(g["eps"]), xp, vp, g["masks"], B)
+    dyn = H.gauge_hip(T, X, N, float(g["eps"]), xp, vp, g["masks"], B, arch=arch)
     dyn.fused = fused
     beta = float(g["beta"])
     S, Tt, Q = dyn.momentum_fn([g["x"], g["grad0"], dyn._format_time(0)])
