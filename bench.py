@@ -66,12 +66,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0 over gloo.
+    backend = os.environ.get("L2HMC_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+    if os.environ.get("L2HMC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from l2hmc_amd import _lib, u1_observables
