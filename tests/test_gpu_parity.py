@@ -471,6 +471,54 @@ def test_philox_stream_bit_exact_and_statistics(la):
     assert not torch.equal(z, z2)
 
 
+# ----------------------------------------------------------------- sampler-level checks
+def test_accept_rate_parity_on_identical_inputs(la):
+    """north_star: accept-rate parity +-1 %.  A 60-step chain on the device; at every step the oracle sees the
+    same state and the same draws (chains would otherwise diverge chaotically after a few accept flips)."""
+    T = X = 8
+    N, eps, beta, B, steps = 10, 0.1, 2.0, 32, 60
+    orc, _, dyn = _pair(T, X, N, eps, B, "mild")
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 2 * np.pi, (B, 128)).astype(np.float32)
+    p_hip, p_orc, acc_hip, acc_orc = [], [], [], []
+    for _ in range(steps):
+        v0f, v0b = rng.standard_normal((B, 128)), rng.standard_normal((B, 128))
+        coin, u = rng.uniform(size=B), rng.uniform(size=B)
+        got = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+        want = orc.apply_transition(x.astype(np.float64), beta, v0f, v0b, coin, u)
+        p_hip.append(np_(got[2]))
+        p_orc.append(want[2])
+        acc_hip.append(np_(got[2]) > u)
+        acc_orc.append(want[2] > u)
+        x = np.mod(got[3].cpu().numpy(), 2 * np.pi).astype(np.float32)     # gauge_model.py:1180
+    p_hip, p_orc = np.concatenate(p_hip), np.concatenate(p_orc)
+    assert 0.02 < p_orc.mean() < 0.98                      # a non-degenerate acceptance regime
+    assert abs(p_hip.mean() - p_orc.mean()) < 1e-4         # bar: 1e-2
+    assert abs(np.mean(acc_hip) - np.mean(acc_orc)) < 2e-3
+    assert np.abs(p_hip - p_orc).max() < 1e-4
+
+
+def test_hmc_sampling_reproduces_exact_plaquette(la):
+    """The reference prints I1(beta)/I0(beta) beside the measured plaquette at every step
+    (lattice.py:31-33, gauge_model.py:1149,1216).  Plain-HMC mode (gauge_dynamics.py:102-108) through the
+    whole device-side MCMC step -- Philox draws, both directions, mixing, MH -- must reproduce it."""
+    beta, L, B = 2.0, 8, 1024
+    lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=B, rand=False)
+    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.12, hmc=True, num_steps=8, eps_trainable=False,
+                           network_arch='generic', seed=5)
+    x = torch.rand(B, 2 * L * L, device="cuda") * (2 * np.pi)
+    plaqs, accs = [], []
+    for step in range(140):
+        _, _, p, x_out = dyn(x, beta)
+        x = torch.remainder(x_out, 2 * np.pi)
+        if step >= 40:
+            plaqs.append(float(la.u1_observables(x, L, L)["avg_plaq"].mean()))
+            accs.append(float(p.mean()))
+    exact = la.u1_plaq_exact(beta)
+    assert 0.5 < np.mean(accs) < 1.0
+    assert abs(np.mean(plaqs) - exact) < 4e-3, (np.mean(plaqs), exact)
+
+
 # ----------------------------------------------------------------- full size (BASELINE.json configs[2])
 def test_full_size_properties_cfg3(la):
     """B=2048, 10 LF steps: size-independent properties instead of an oracle run."""
