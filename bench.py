@@ -81,8 +81,7 @@ def main():
             dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from l2hmc_amd import _lib, u1_observables
-    from l2hmc_amd.dist import StepStats
+    from l2hmc_amd import _lib, GaugeSampler, stats as chain_stats
     dev = torch.device("cuda", local_rank)
     both = not args.selected_only
     dyn, xp, vp, masks = build_dynamics(BATCH, both)
@@ -92,15 +91,11 @@ def main():
     x = torch.empty(BATCH, D, device=dev)
     _lib.check(_lib.lib().l2hmc_fill_uniform(x.data_ptr(), x.numel(), 103 + rank, 0, _lib.stream_ptr()))
     x.mul_(2 * np.pi)                             # hot start, lattice.py:131-135
-    stats = StepStats(dev, dist)
+    sampler = GaugeSampler(dyn, dist=dist)       # transition + device-side wrap + per-step observables
+    stats = sampler.stats                        # one fused all-reduce of the step's scalar sums
 
     def step(x):
-        x_prop, v_prop, p, x_out = dyn(x, BETA)
-        q_old = u1_observables(x, L, L)["top_charge"]
-        x_new = torch.remainder(x_out, 2 * np.pi)              # gauge_model.py:1180
-        obs = u1_observables(x_new, L, L)                      # per-step observables, :256-266
-        stats.push(p, torch.abs(obs["top_charge"] - q_old))    # one fused all-reduce per step
-        return x_new
+        return sampler.step(x, BETA)[0]
 
     for _ in range(args.warmup):
         x = step(x)
@@ -108,9 +103,11 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    history = []                                  # references only: no device work in the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x = step(x)
+        history.append(x)
     stats.wait()
     torch.cuda.synchronize()
     if dist is not None:
@@ -138,6 +135,18 @@ def main():
                    "parallelism": f"chains sharded over {world} GPU(s), weights replicated",
                    "mean_accept_prob": accept_rate},
     }
+
+    # ---- secondary metric: ESS/sec with the reference's estimator (func_utils.py:45-54,114-120) on
+    #      (cos, sin) of the links of rank 0's chains over the timed steps, normalised by the lag-0 term
+    if rank == 0 and args.steps >= 8:
+        X = torch.stack(history[-min(args.steps, 64):]).cpu().numpy()
+        feats = np.concatenate([np.cos(X), np.sin(X)], axis=2)
+        feats = feats - feats.mean(axis=(0, 1), keepdims=True)
+        A = chain_stats.acl_spectrum(feats, 1.0)
+        ess = float(chain_stats.ESS(A / A[0]))
+        out["config"]["ess_per_mcmc_step"] = ess
+        out["config"]["ess_per_sec_whole_job"] = ess * world * BATCH * args.steps / dt
+    history.clear()
 
     # ---- roofline of the dominant kernel, HIP events on the launch stream ----
     if rank == 0 and not args.no_roofline:

@@ -63,6 +63,10 @@ int l2hmc_u1_action_force(const float* x, int64_t rows, int32_t T, int32_t X, fl
 int l2hmc_u1_plaq_sums(const float* x, int64_t rows, int32_t T, int32_t X, float* plaq,
                        l2hmc_stream_t stream);
 
+/* gauge_model.py:1180,1388: samples = np.mod(x_out, 2*pi) between MCMC steps, done on the device
+ * (fp32, result in [0, 2*pi)).  out may alias x. */
+int l2hmc_wrap_angle(const float* x, int64_t n, float* out, l2hmc_stream_t stream);
+
 /* gauge_dynamics.py:683-689 / utils/dynamics.py:112-113: out[r] = 0.5 * sum_d v^2. */
 int l2hmc_kinetic_energy(const float* v, int64_t rows, int32_t D, float* out, l2hmc_stream_t stream);
 

@@ -56,6 +56,7 @@ _PROTOS = {
     "l2hmc_last_error": (C.c_char_p, []),
     "l2hmc_u1_action_force": (C.c_int, [_P, _I64, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     "l2hmc_u1_plaq_sums": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
+    "l2hmc_wrap_angle": (C.c_int, [_P, _I64, _P, _P]),
     "l2hmc_kinetic_energy": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "l2hmc_stq_ws_bytes": (_SZ, [_I64, _I32]),
     "l2hmc_stq_dense": (C.c_int, [C.POINTER(DenseNet), _P, _P, _P, _F, _F, _I64, _P, _P, _P, _P, _SZ, _P]),

@@ -131,6 +131,16 @@ __global__ __launch_bounds__(256) void mix_accept_kernel(
   }
 }
 
+// np.mod(x, 2*pi) in fp32 (gauge_model.py:1180,1388: the host-side wrap between MCMC steps)
+__global__ __launch_bounds__(256) void wrap_angle_kernel(const float* x, int64_t n, float* out) {
+  const float two_pi = 6.28318530717958647692f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float r = fmodf(x[i], two_pi);
+    if (r < 0.f) r += two_pi;
+    out[i] = r;
+  }
+}
+
 // selected-direction mode: dir = coin > 0.5 ? fwd : bwd; v0 = that direction's momentum
 __global__ __launch_bounds__(256) void select_dir_kernel(const float* __restrict__ coin,
                                                          const float* __restrict__ v0_f,
@@ -443,6 +453,16 @@ extern "C" int l2hmc_mix_accept(const float* x, const float* xf, const float* vf
   hipLaunchKernelGGL(mix_accept_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, x,
                      xf, vf, pf, xb, vb, pb, coin, u, strict, B, D, x_prop, v_prop, p, x_out);
   L2HMC_CHECK_LAUNCH("mix_accept");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_wrap_angle(const float* x, int64_t n, float* out, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(n >= 0, "wrap_angle: n < 0");
+  if (n == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && out, "wrap_angle: NULL pointer");
+  hipLaunchKernelGGL(wrap_angle_kernel, dim3((unsigned)hmin(ceil_div(n, 256), 2048)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, out);
+  L2HMC_CHECK_LAUNCH("wrap_angle");
   return L2HMC_OK;
 }
 

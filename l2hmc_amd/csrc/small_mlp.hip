@@ -8,29 +8,34 @@
 //   autodiff there, closed form here)
 // These configurations (x_dim 2, 10-50 hidden units) are launch/latency bound:
 // an MFMA tile would be >90 % padding, so the MLP runs on the VALU with both
-// networks' weights resident in LDS (broadcast reads) and the chain state in
-// registers; x and v are read once and written once per trajectory.
+// networks' weights resident in LDS and the chain state in registers; x and v
+// are read once and written once per trajectory.  Sixteen lanes cooperate on a
+// chain: each owns HP/16 hidden units (first and hidden layer), the hidden
+// vector is exchanged through a 256-byte LDS row, and the heads are k-split
+// over the lanes and combined with a 16-lane xor-shuffle butterfly, so every
+// lane ends up with S, T, Q and applies the (cheap) update redundantly.
 #include "common.h"
 
 namespace l2hmc {
 
-constexpr int kSmallThreads = 64;
+constexpr int kSmallThreads = 256;   // 16 chains per workgroup
+constexpr int kLPC = 16;              // lanes per chain
 constexpr int kMaxDim = L2HMC_MAX_SMALL_DIM;
 constexpr int kMaxMix = L2HMC_MAX_MIX;
 
-struct SmallNetView {   // offsets (floats) into the per-net LDS image
+struct SmallNetView {   // offsets (floats) into the per-net LDS image; weight matrices are k-major [k][HP]
   int w1, wt, b1, wh, bh, whd, bhd, es, eq, size;
 };
 
 __host__ __device__ inline SmallNetView small_net_view(int HP, int dim) {
   SmallNetView v;
   int o = 0;
-  v.w1 = o; o += HP * 2 * dim;
-  v.wt = o; o += 2 * HP;
+  v.w1 = o; o += 2 * dim * HP;      // [2*dim][HP]
+  v.wt = o; o += 2 * HP;            // [2][HP]
   v.b1 = o; o += HP;
-  v.wh = o; o += HP * HP;
+  v.wh = o; o += HP * HP;           // [k][n]
   v.bh = o; o += HP;
-  v.whd = o; o += 3 * dim * HP;
+  v.whd = o; o += 3 * dim * HP;     // [3*dim][k]
   v.bhd = o; o += 3 * dim;
   v.es = o; o += dim;
   v.eq = o; o += dim;
@@ -44,13 +49,14 @@ __device__ void load_net(const l2hmc_dense_net& n, float* L, int dim) {
   const int H = n.H, tid = threadIdx.x;
   for (int i = tid; i < v.size; i += kSmallThreads) L[i] = 0.f;
   __syncthreads();
-  for (int i = tid; i < H * 2 * dim; i += kSmallThreads) L[v.w1 + i] = n.w1_t[i];
+  // packed global layouts: w1_t [H][2*dim], wh_t [H (out)][H (in)], whd_t [3][dim][H]
+  for (int i = tid; i < H * 2 * dim; i += kSmallThreads) L[v.w1 + (i % (2 * dim)) * HP + i / (2 * dim)] = n.w1_t[i];
   for (int i = tid; i < 2 * H; i += kSmallThreads) L[v.wt + (i / H) * HP + (i % H)] = n.wt[i];
   for (int i = tid; i < H; i += kSmallThreads) {
     L[v.b1 + i] = n.b1[i];
     L[v.bh + i] = n.bh[i];
   }
-  for (int i = tid; i < H * H; i += kSmallThreads) L[v.wh + (i / H) * HP + (i % H)] = n.wh_t[i];
+  for (int i = tid; i < H * H; i += kSmallThreads) L[v.wh + (i % H) * HP + i / H] = n.wh_t[i];
   for (int i = tid; i < 3 * dim * H; i += kSmallThreads) L[v.whd + (i / H) * HP + (i % H)] = n.whd_t[i];
   for (int i = tid; i < 3 * dim; i += kSmallThreads) L[v.bhd + i] = n.bhd[i];
   for (int i = tid; i < dim; i += kSmallThreads) {
@@ -59,41 +65,63 @@ __device__ void load_net(const l2hmc_dense_net& n, float* L, int dim) {
   }
 }
 
-// (S, T, Q) = net([a, b, t]); h2 goes through a per-thread LDS column.
+// (S, T, Q) = net([a, b, t]) for the chain this lane belongs to.  `sub` = lane within the chain (0..15),
+// `hrow` = the chain's HP-float LDS row for the hidden-vector exchange.  Must be called by all threads of the
+// workgroup (it contains workgroup barriers).
 template <int HP>
-__device__ void net_eval(const float* L, int dim, int H, int q_tanh, const float a[kMaxDim],
-                         const float b[kMaxDim], float tc, float ts, float* h2col, float S[kMaxDim],
-                         float T[kMaxDim], float Q[kMaxDim]) {
+__device__ void net_eval(const float* L, int dim, int q_tanh, const float a[kMaxDim], const float b[kMaxDim],
+                         float tc, float ts, int sub, float* hrow, float S[kMaxDim], float T[kMaxDim],
+                         float Q[kMaxDim]) {
+  constexpr int UPL = HP / kLPC;           // hidden units per lane: n = sub * UPL + j
   const SmallNetView v = small_net_view(HP, dim);
-  float h1[HP];
+  const int n0 = sub * UPL;
+  float h[UPL];
 #pragma unroll
-  for (int n = 0; n < HP; ++n) {
-    float acc = L[v.b1 + n] + tc * L[v.wt + n] + ts * L[v.wt + HP + n];
+  for (int j = 0; j < UPL; ++j) h[j] = L[v.b1 + n0 + j] + tc * L[v.wt + n0 + j] + ts * L[v.wt + HP + n0 + j];
 #pragma unroll
-    for (int k = 0; k < kMaxDim; ++k)
-      if (k < dim) acc += a[k] * L[v.w1 + n * 2 * dim + k] + b[k] * L[v.w1 + n * 2 * dim + dim + k];
-    h1[n] = fmaxf(acc, 0.f);
+  for (int k = 0; k < kMaxDim; ++k) {
+    if (k < dim) {
+#pragma unroll
+      for (int j = 0; j < UPL; ++j)
+        h[j] += a[k] * L[v.w1 + k * HP + n0 + j] + b[k] * L[v.w1 + (dim + k) * HP + n0 + j];
+    }
   }
-  for (int n = 0; n < H; ++n) {
-    float acc = L[v.bh + n];
-    const float* w = L + v.wh + n * HP;
+  __syncthreads();                          // previous readers of hrow are done
 #pragma unroll
-    for (int k = 0; k < HP; ++k) acc += h1[k] * w[k];
-    h2col[n * kSmallThreads] = fmaxf(acc, 0.f);
+  for (int j = 0; j < UPL; ++j) hrow[n0 + j] = fmaxf(h[j], 0.f);
+  __syncthreads();
+  float h2[UPL];
+#pragma unroll
+  for (int j = 0; j < UPL; ++j) h2[j] = L[v.bh + n0 + j];
+  for (int k = 0; k < HP; ++k) {
+    const float hk = hrow[k];               // broadcast within the chain's 16 lanes
+    const float* w = L + v.wh + k * HP + n0;
+#pragma unroll
+    for (int j = 0; j < UPL; ++j) h2[j] += hk * w[j];
   }
+#pragma unroll
+  for (int j = 0; j < UPL; ++j) h2[j] = fmaxf(h2[j], 0.f);
+  // heads: k-split over the lanes, 16-lane butterfly
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) {
     if (d < dim) {
-      float s = L[v.bhd + d], t = L[v.bhd + dim + d], q = L[v.bhd + 2 * dim + d];
-      const float* ws = L + v.whd + (0 * dim + d) * HP;
-      const float* wt = L + v.whd + (1 * dim + d) * HP;
-      const float* wq = L + v.whd + (2 * dim + d) * HP;
-      for (int k = 0; k < H; ++k) {
-        const float h = h2col[k * kSmallThreads];
-        s += h * ws[k];
-        t += h * wt[k];
-        q += h * wq[k];
+      float ps = 0.f, pt = 0.f, pq = 0.f;
+      const float* ws = L + v.whd + (0 * dim + d) * HP + n0;
+      const float* wt = L + v.whd + (1 * dim + d) * HP + n0;
+      const float* wq = L + v.whd + (2 * dim + d) * HP + n0;
+#pragma unroll
+      for (int j = 0; j < UPL; ++j) {
+        ps += h2[j] * ws[j];
+        pt += h2[j] * wt[j];
+        pq += h2[j] * wq[j];
       }
+#pragma unroll
+      for (int off = kLPC / 2; off > 0; off >>= 1) {
+        ps += __shfl_xor(ps, off, 64);
+        pt += __shfl_xor(pt, off, 64);
+        pq += __shfl_xor(pq, off, 64);
+      }
+      const float s = ps + L[v.bhd + d], t = pt + L[v.bhd + dim + d], q = pq + L[v.bhd + 2 * dim + d];
       S[d] = tanhf(s) * L[v.es + d];
       T[d] = t;
       Q[d] = (q_tanh ? tanhf(q) : q) * L[v.eq + d];
@@ -198,14 +226,14 @@ template <int HP>
 __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs a) {
   extern __shared__ float lds[];
   const l2hmc_small_plan& P = a.plan;
-  const int dim = P.x_dim, H = P.num_nodes, N = P.trajectory_length;
+  const int dim = P.x_dim, N = P.trajectory_length;
   const SmallNetView nv = small_net_view(HP, dim);
   const TargetView tv = target_view(P.target.dim, P.target.K);
   float* Lx = lds;
   float* Lv = Lx + nv.size;
   float* Lt = Lv + nv.size;
   float* Lm = Lt + tv.size;                       // masks [N][dim]
-  float* h2 = Lm + ((N * dim + 3) & ~3);          // [HP][64] per-thread columns
+  float* hx = Lm + ((N * dim + 3) & ~3);          // [16 chains][HP] hidden-vector exchange rows
   if (!P.hmc) {
     load_net<HP>(P.xnet, Lx, dim);
     load_net<HP>(P.vnet, Lv, dim);
@@ -214,10 +242,11 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
   for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
   __syncthreads();
 
-  const int64_t r = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
-  if (r >= a.rows) return;
-  float* h2col = h2 + threadIdx.x;
-  const int bwd = a.dir ? a.dir[r] : 0;
+  const int lsub = threadIdx.x & (kLPC - 1), slot = threadIdx.x / kLPC;   // lane within the chain
+  const int64_t r = (int64_t)blockIdx.x * (kSmallThreads / kLPC) + slot;
+  const bool live = r < a.rows;                   // dead chains still walk through the barriers
+  float* hrow = hx + slot * HP;
+  const int bwd = (a.dir && live) ? a.dir[r] : 0;
   const float eps = P.eps;
   const float inv_temp = 1.f / P.target.temperature;
   const int isg = P.target.is_gaussian, K = P.target.K;
@@ -225,8 +254,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
   float x[kMaxDim], v[kMaxDim];
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) {
-    x[d] = d < dim ? a.x0[r * dim + d] : 0.f;
-    v[d] = d < dim ? a.v0[r * dim + d] : 0.f;
+    x[d] = (d < dim && live) ? a.x0[r * dim + d] : 0.f;
+    v[d] = (d < dim && live) ? a.v0[r * dim + d] : 0.f;
   }
   float g[kMaxDim], E0, E1;
   energy_grad(Lt, dim, K, isg, inv_temp, x, &E0, g);
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
             const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
             bin[d] = k * x[d];
           }
-          if (!P.hmc) net_eval<HP>(Lx, dim, H, P.xnet.q_tanh, v, bin, tc, ts, h2col, S, T, Q);
+          if (!P.hmc) net_eval<HP>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
           for (int d = 0; d < kMaxDim; ++d) {
             if (d < dim) {
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
         }
         energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
       }
-      if (!P.hmc) net_eval<HP>(Lv, dim, H, P.vnet.q_tanh, x, g, tc, ts, h2col, S, T, Q);
+      if (!P.hmc) net_eval<HP>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) {
         if (d < dim) {
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) kin1 += v[d] * v[d];
   const float H1 = E1 + 0.5f * kin1;
+  if (!live || lsub != 0) return;                  // every lane of the chain holds the same result
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) {
     if (d < dim) {
@@ -354,9 +384,9 @@ extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float*
   SmallTrajArgs a{*plan, x0, v0, dir, rows, x_out, v_out, sumlogdet, p_accept};
   const size_t lds = sizeof(float) * (2 * (size_t)small_net_view(HP, dim).size +
                                       target_view(dim, plan->target.K).size + ((N * dim + 3) & ~3) +
-                                      (size_t)HP * kSmallThreads);
+                                      (size_t)HP * (kSmallThreads / kLPC));
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
-  const dim3 grid((unsigned)ceil_div(rows, kSmallThreads));
+  const dim3 grid((unsigned)ceil_div(rows, kSmallThreads / kLPC));
   static bool attr_set = false;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16>),

@@ -128,6 +128,94 @@ __global__ __launch_bounds__(kLatThreads) void u1_action_force_kernel(
   }
 }
 
+// Fast path for lattices whose site count divides the workgroup (8x8: 4 chains, 16x16: 1 chain per pass):
+// one site per thread, every index and neighbour offset is loop-invariant, workgroups are persistent
+// (grid-stride over chain groups, the next group's links are in flight while the current one is computed),
+// and the scalar observables are compiled out when only the force is wanted (the integrator's case).
+template <bool SCALARS>
+__global__ __launch_bounds__(kLatThreads) void u1_fast_kernel(
+    const float* __restrict__ x, int64_t rows, int T, int X, float beta, int cpw,
+    float* __restrict__ action, float* __restrict__ force, float* __restrict__ avg_plaq,
+    float* __restrict__ top_charge) {
+  __shared__ float2 xs[2][kLatThreads];
+  __shared__ float sp[2][kLatThreads];
+  __shared__ float red[kLatThreads / kWave][3];
+  const int sites = T * X;
+  const int tid = threadIdx.x;
+  const int c = tid / sites, site = tid - c * sites;
+  const int i = site / X, j = site - i * X;
+  const int base = c * sites;
+  const int n_jp = base + i * X + ((j + 1 == X) ? 0 : j + 1);
+  const int n_ip = base + ((i + 1 == T) ? 0 : i + 1) * X + j;
+  const int n_jm = base + i * X + ((j == 0) ? X - 1 : j - 1);
+  const int n_im = base + ((i == 0) ? T - 1 : i - 1) * X + j;
+  const int64_t ngroups = (rows + cpw - 1) / cpw;
+  const float2* x2 = reinterpret_cast<const float2*>(x);
+  float2* f2 = reinterpret_cast<float2*>(force);
+  const float inv_two_pi = 0.15915494309189533577f;
+
+  int64_t grp = blockIdx.x;
+  float2 nxt = make_float2(0.f, 0.f);
+  if (grp < ngroups) {
+    const int64_t row = grp * cpw + c;
+    if (row < rows) nxt = x2[row * sites + site];
+  }
+  int buf = 0;
+  for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
+    const int64_t row = grp * cpw + c;
+    const float2 xv = nxt;
+    xs[buf][tid] = xv;
+    const int64_t g2 = grp + gridDim.x;           // prefetch the next group's links
+    nxt = make_float2(0.f, 0.f);
+    if (g2 < ngroups) {
+      const int64_t r2 = g2 * cpw + c;
+      if (r2 < rows) nxt = x2[r2 * sites + site];
+    }
+    __syncthreads();
+    const float P = xv.x - xv.y - xs[buf][n_jp].x + xs[buf][n_ip].y;
+    float sn, cs = 0.f;
+    if (SCALARS) sincosf(P, &sn, &cs);
+    else sn = sinf(P);
+    sp[buf][tid] = sn;
+    if (SCALARS) {
+      float a = wave_sum(1.f - cs), q = wave_sum(cs);
+      float ch = wave_sum(P - kTwoPi * floorf((P + kPi) * inv_two_pi));
+      if (sites == kWave) {
+        if ((tid & 63) == 0 && row < rows) {
+          if (action) action[row] = a;
+          if (avg_plaq) avg_plaq[row] = q / (float)sites;
+          if (top_charge) top_charge[row] = ch * inv_two_pi;
+        }
+      } else if ((tid & 63) == 0) {
+        red[tid >> 6][0] = a;
+        red[tid >> 6][1] = q;
+        red[tid >> 6][2] = ch;
+      }
+    }
+    __syncthreads();
+    if (SCALARS && sites != kWave && site == 0 && row < rows) {
+      const int w0 = base / kWave, nw = sites / kWave;
+      float a = 0.f, q = 0.f, ch = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        a += red[w0 + w][0];
+        q += red[w0 + w][1];
+        ch += red[w0 + w][2];
+      }
+      if (action) action[row] = a;
+      if (avg_plaq) avg_plaq[row] = q / (float)sites;
+      if (top_charge) top_charge[row] = ch * inv_two_pi;
+    }
+    if (force && row < rows) {
+      float2 g;
+      g.x = beta * (sn - sp[buf][n_jm]);
+      g.y = beta * (-sn + sp[buf][n_im]);
+      f2[row * sites + site] = g;
+    }
+    // xs/sp are double-buffered: the next iteration writes the other buffer, and its first barrier orders
+    // this iteration's reads of `red` against the next writes
+  }
+}
+
 __global__ __launch_bounds__(256) void u1_plaq_sums_kernel(const float* __restrict__ x, int64_t rows,
                                                            int T, int X, float* __restrict__ plaq) {
   const int sites = T * X;
@@ -163,6 +251,22 @@ __global__ __launch_bounds__(256) void kinetic_kernel(const float* __restrict__ 
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream) {
   const int sites = T * X;
+  if (sites % kWave == 0 && kLatThreads % sites == 0) {
+    const int cpwf = kLatThreads / sites;
+    const int64_t ngroups = ceil_div(rows, cpwf);
+    const unsigned gridf = (unsigned)hmin(ngroups, 256 * 8);
+    const bool scalars = action || avg_plaq || top_charge;
+    prof_before(kProfU1, stream);
+    if (scalars)
+      hipLaunchKernelGGL(u1_fast_kernel<true>, dim3(gridf), dim3(kLatThreads), 0, stream, x, rows, T, X, beta, cpwf,
+                         action, force, avg_plaq, top_charge);
+    else
+      hipLaunchKernelGGL(u1_fast_kernel<false>, dim3(gridf), dim3(kLatThreads), 0, stream, x, rows, T, X, beta,
+                         cpwf, action, force, avg_plaq, top_charge);
+    prof_after(kProfU1, stream);
+    L2HMC_CHECK_LAUNCH("u1_action_force");
+    return L2HMC_OK;
+  }
   const int cpw = sites >= kLatThreads ? 1 : kLatThreads / sites;
   const size_t lds = sizeof(float) * ((size_t)cpw * 3 * sites + 3 * kLatThreads);
   L2HMC_REQUIRE(lds <= 160 * 1024, "u1_action_force: lattice %dx%d does not fit LDS", T, X);

@@ -1,0 +1,71 @@
+"""Device-resident sampling loop: the step harness around the hot path
+(l2hmc/gauge_model.py:1304-1460 `GaugeModel.run`, the inference half of SURVEY.md 8f/f3).
+
+The reference runs one `sess.run` per MCMC step, copying the whole sample batch host<->device through
+`feed_dict` and wrapping it with `np.mod(., 2*pi)` on the host (:1371-1388).  Here the chain state never
+leaves HBM: transition -> wrap -> per-step observables are all library calls on device buffers, and the
+per-step scalars of all ranks are combined by one small asynchronous all-reduce (l2hmc_amd/dist.py)."""
+import numpy as np
+import torch
+
+from . import _lib
+from .dist import StepStats
+from .lattice import u1_observables, u1_plaq_exact
+
+
+class GaugeSampler:
+    def __init__(self, dynamics, beta_init=2., beta_final=4., train_steps=10000, dist=None):
+        self.dynamics = dynamics
+        self.lattice = dynamics.lattice
+        self.beta_init, self.beta_final, self.train_steps = beta_init, beta_final, train_steps
+        self.stats = StepStats(dynamics._device, dist)
+
+    def update_beta(self, step):
+        """gauge_model.py:1039-1046: linear annealing of 1/beta."""
+        temp = ((1. / self.beta_init - 1. / self.beta_final) * (1. - step / float(self.train_steps))
+                + 1. / self.beta_final)
+        return 1. / temp
+
+    def wrap(self, x):
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().l2hmc_wrap_angle(x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    def step(self, x, beta):
+        """One MCMC step on device state x: [B, x_dim].  Returns (x_next, px, observables of x, |dQ|);
+        as in the reference the action / plaquette / charge ops look at the step's INPUT samples
+        (gauge_model.py:256-266) and dQ compares input and output (:718-725)."""
+        T, X = self.lattice.time_size, self.lattice.space_size
+        _, _, px, x_out = self.dynamics(x, beta)
+        obs = u1_observables(x, T, X)
+        x_next = self.wrap(x_out)
+        dq = torch.abs(u1_observables(x_out, T, X)["top_charge"] - obs["top_charge"])
+        self.stats.push(px, dq)
+        return x_next, px, obs, dq
+
+    def run(self, run_steps, beta, x=None, keep_samples=False):
+        """:1304-1460 without the file/plot side effects.  Starts from N(0,1) samples like the reference
+        (:1354) unless `x` is given.  Returns per-step histories as NumPy arrays [steps, B]."""
+        dyn = self.dynamics
+        if x is None:
+            x = _lib.as_dev(np.random.randn(dyn.batch_size, dyn.x_dim), dyn._device)
+        else:
+            x = _lib.as_dev(x, dyn._device)
+        hist = {k: [] for k in ("px", "actions", "plaqs", "charges", "charge_diff")}
+        samples = []
+        for _ in range(run_steps):
+            x, px, obs, dq = self.step(x, beta)
+            hist["px"].append(px)
+            hist["actions"].append(obs["action"])
+            hist["plaqs"].append(obs["avg_plaq"])
+            hist["charges"].append(obs["top_charge"])
+            hist["charge_diff"].append(dq)
+            if keep_samples:
+                samples.append(x)
+        out = {k: torch.stack(v).cpu().numpy() for k, v in hist.items()}
+        out["plaq_exact"] = u1_plaq_exact(beta)
+        out["samples_out"] = x
+        out["mean_accept"] = self.stats.mean_accept()
+        if keep_samples:
+            out["samples"] = torch.stack(samples).cpu().numpy()
+        return out

@@ -476,8 +476,8 @@ def test_accept_rate_parity_on_identical_inputs(la):
     """north_star: accept-rate parity +-1 %.  A 60-step chain on the device; at every step the oracle sees the
     same state and the same draws (chains would otherwise diverge chaotically after a few accept flips)."""
     T = X = 8
-    N, eps, beta, B, steps = 10, 0.1, 2.0, 32, 60
-    orc, _, dyn = _pair(T, X, N, eps, B, "mild")
+    N, eps, beta, B, steps = 5, 0.08, 2.0, 32, 60
+    orc, _, dyn = _pair(T, X, N, eps, B, "init")
     rng = np.random.default_rng(11)
     x = rng.uniform(0, 2 * np.pi, (B, 128)).astype(np.float32)
     p_hip, p_orc, acc_hip, acc_orc = [], [], [], []
@@ -517,6 +517,31 @@ def test_hmc_sampling_reproduces_exact_plaquette(la):
     exact = la.u1_plaq_exact(beta)
     assert 0.5 < np.mean(accs) < 1.0
     assert abs(np.mean(plaqs) - exact) < 4e-3, (np.mean(plaqs), exact)
+
+
+def test_device_resident_sampling_loop(la):
+    """GaugeSampler.run (gauge_model.py:1304-1460 without files/plots): wrap on the device equals np.mod,
+    histories have the reference's shapes, beta annealing follows :1039-1046."""
+    T = X = 8
+    B = 48
+    orc, _, dyn = _pair(T, X, 3, 0.1, B, "mild")
+    smp = la.GaugeSampler(dyn, beta_init=2., beta_final=4., train_steps=100)
+    assert abs(smp.update_beta(0) - 2.0) < 1e-12 and abs(smp.update_beta(100) - 4.0) < 1e-12
+    assert abs(1. / smp.update_beta(50) - 0.5 * (1 / 2. + 1 / 4.)) < 1e-12
+    xs = torch.randn(B, 128, device="cuda") * 20.
+    w = smp.wrap(xs)
+    np.testing.assert_allclose(np_(w), np.mod(xs.cpu().numpy(), np.float32(2 * np.pi)), atol=2e-6)
+    assert float(w.min()) >= 0 and float(w.max()) < 2 * np.pi + 1e-6
+    out = smp.run(5, 2.0, keep_samples=True)
+    assert out["px"].shape == (5, B) and out["samples"].shape == (5, B, 128)
+    assert np.all((out["px"] >= 0) & (out["px"] <= 1)) and abs(out["plaq_exact"] - 0.697775) < 1e-6
+    # observables of step k are those of step k-1's output samples
+    S = olat.total_action(out["samples"][2].astype(np.float64), T, X)
+    assert H.relerr(out["actions"][3], S) < TOL_OP
+    q = olat.top_charge(out["samples"][2].astype(np.float64), T, X)
+    assert H.relerr(out["charges"][3], q) < 1e-4
+    ess = la.stats.ESS(la.stats.acl_spectrum(out["samples"], 1.0) / la.stats.autocovariance(out["samples"], 0))
+    assert 0 < ess <= 1.0
 
 
 # ----------------------------------------------------------------- full size (BASELINE.json configs[2])

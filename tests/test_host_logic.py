@@ -85,6 +85,30 @@ def test_mask_and_time_tables_follow_reference_streams():
     assert a.sum() == 10 * 64 and set(np.unique(a)) == {0.0, 1.0}
 
 
+def test_ess_estimators_follow_reference_definitions():
+    """func_utils.py:45-54,114-120 restated as loops here, vectorised in l2hmc_amd/stats.py."""
+    from l2hmc_amd import stats
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((12, 5, 3))
+
+    def autocov_ref(X, tau):
+        dT, dN, dX = X.shape
+        s = 0.
+        for t in range(dT - tau):
+            s += np.sum(X[t] * X[t + tau]) / dN
+        return s / (dT - tau)
+
+    for tau in (0, 1, 5, 11):
+        assert abs(stats.autocovariance(X, tau) - autocov_ref(X, tau)) < 1e-12
+    A = stats.acl_spectrum(X, 2.0)
+    assert A.shape == (11,) and abs(A[3] - autocov_ref(X / 2.0, 3)) < 1e-12
+    a = np.array([1.0, 0.5, 0.04, 0.2, -0.3])
+    assert abs(stats.ESS(a) - 1. / (1. + 2 * (0.5 + 0.2))) < 1e-12       # entries <= 0.05 are dropped
+    # an i.i.d. series has ESS ~ 1 per step once normalised by its variance
+    Y = rng.standard_normal((400, 64, 1))
+    assert 0.5 < stats.ESS(stats.acl_spectrum(Y, np.sqrt(stats.autocovariance(Y, 0)))) <= 1.0
+
+
 def test_shard_bounds_partition_the_chains():
     for n, w in ((2048, 8), (8192, 8), (10, 3), (5, 8), (0, 2)):
         spans = [shard_bounds(n, w, r) for r in range(w)]
