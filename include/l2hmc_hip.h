@@ -214,6 +214,17 @@ int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, const float
                            int32_t both_directions, float* x_prop, float* v_prop, float* p_accept,
                            float* x_out, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
 
+/* One MCMC step of the sampling loop on device-resident chains (gauge_model.py:1371-1388 around
+ * apply_transition): draws (Philox streams (seed, 2*draw) for the stacked momenta [v0_f; v0_b] and
+ * (seed, 2*draw+1) for coin | u -- reproducible with l2hmc_fill_normal/_uniform), both trajectories, mix,
+ * accept/reject, then x <- mod(x_out, 2*pi) IN PLACE.  Per-chain outputs (any may be NULL): px = accept
+ * probability; actions / plaqs / charges = observables of the step's INPUT samples (as :256-266);
+ * charge_diff = |Q(x_in) - Q(x_out)| (:718-725).  Three launches when the plan has a fused kernel. */
+size_t l2hmc_gauge_mcmc_step_ws_bytes(const l2hmc_gauge_plan* plan, int64_t B);
+int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, int64_t B, uint64_t seed,
+                          uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
+                          float* charge_diff, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Generic integrator on 2-D toy targets (MoG / SCG):
  *   utils/dynamics.py:120-225,255-319; utils/sampler.py:28-59;

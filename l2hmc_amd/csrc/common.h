@@ -48,6 +48,37 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11) and the word -> float maps shared by every generator in the library
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0;
+    k1 += W1;
+  }
+}
+
+__device__ __forceinline__ float u01_open(uint32_t w) {   // (0, 1): 24 bits, centred
+  return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// four standard normals from one Philox block (Box-Muller on word pairs)
+__device__ __forceinline__ void philox_normal4(const uint32_t c[4], float v[4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = u01_open(c[2 * h]), u2 = u01_open(c[2 * h + 1]);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    v[2 * h] = rad * cs;
+    v[2 * h + 1] = rad * sn;
+  }
+}
+
 // exp(min(dh, 0)) with the reference's NaN semantics: tf.minimum propagates NaN and
 // gauge_dynamics.py:609 / utils/dynamics.py:319 then map every non-finite result to 0.
 template <typename T>

@@ -187,6 +187,8 @@ struct FusedArgs {
   l2hmc_dense_net xnet, vnet;            // .packed must be set
   const float* x0; const float* v0;      // [rows][D]
   const int* dir;                        // [rows] or NULL
+  int64_t x_mod;                         // > 0: row r starts from x0[r % x_mod] (both directions of one batch)
+  int64_t dir_split;                     // dir == NULL and > 0: rows >= dir_split integrate backward
   int64_t rows;
   float* x_out; float* v_out;            // [rows][D]
   float* logdet;                         // [rows] or NULL; written (=) or accumulated (+=)
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
     f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
     if (rr < nrow) {
-      xv = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + rr) * D + c4);
+      const int64_t xr = p.x_mod > 0 ? (row0 + rr) % p.x_mod : row0 + rr;
+      xv = *reinterpret_cast<const f32x4*>(p.x0 + xr * D + c4);
       vv = *reinterpret_cast<const f32x4*>(p.v0 + (row0 + rr) * D + c4);
     }
     *reinterpret_cast<f32x4*>(xs + rr * SX + c4) = xv;
@@ -266,7 +269,11 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   };
   load_consts(p.xnet, cx);
   load_consts(p.vnet, cv);
-  if (tid < kFM) sdir[tid] = (p.dir && tid < nrow) ? p.dir[row0 + tid] : 0;
+  if (tid < kFM) {
+    int d = 0;
+    if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
+    sdir[tid] = d;
+  }
   if (tid < kFWaves * kFM) ldw[tid] = 0.f;
   __syncthreads();
 
@@ -584,7 +591,7 @@ int fused_plan_supported(const l2hmc_gauge_plan* p) {
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
                             float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
-                            hipStream_t stream) {
+                            hipStream_t stream, int64_t x_mod, int64_t dir_split) {
   using Cfg = FusedCfg<128, 512>;
   static bool attr_set = false;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
@@ -600,6 +607,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = step_begin; a.step_end = step_end;
   a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
   a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
+  a.x_mod = x_mod; a.dir_split = dir_split;
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
 #ifdef L2HMC_STAMPS
   a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;

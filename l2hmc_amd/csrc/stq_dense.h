@@ -92,7 +92,7 @@ int fused_plan_supported(const l2hmc_gauge_plan* p);
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
                             float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
-                            hipStream_t stream);
+                            hipStream_t stream, int64_t x_mod = 0, int64_t dir_split = 0);
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream);
 

@@ -32,11 +32,15 @@ class StepStats:
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.total = torch.zeros(3, dtype=torch.float64)
         self._pending = []
+        self._count, self._count_n = None, -1
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def push(self, p_accept, abs_dq):
-        buf = torch.stack([p_accept.sum(dtype=torch.float32), abs_dq.sum(dtype=torch.float32),
-                           torch.tensor(float(p_accept.numel()), dtype=torch.float32, device=p_accept.device)])
+        n = p_accept.numel()
+        if self._count is None or self._count_n != n or self._count.device != p_accept.device:
+            self._count = torch.full((1,), float(n), dtype=torch.float32, device=p_accept.device)   # once per batch size
+            self._count_n = n
+        buf = torch.cat([torch.stack((p_accept, abs_dq)).sum(dim=1, dtype=torch.float32), self._count])
         work = None
         if self.dist is not None:
             if self._side is not None:

@@ -19,6 +19,7 @@ class GaugeSampler:
         self.lattice = dynamics.lattice
         self.beta_init, self.beta_final, self.train_steps = beta_init, beta_final, train_steps
         self.stats = StepStats(dynamics._device, dist)
+        self._step_count = 0
 
     def update_beta(self, step):
         """gauge_model.py:1039-1046: linear annealing of 1/beta."""
@@ -34,7 +35,28 @@ class GaugeSampler:
     def step(self, x, beta):
         """One MCMC step on device state x: [B, x_dim].  Returns (x_next, px, observables of x, |dQ|);
         as in the reference the action / plaquette / charge ops look at the step's INPUT samples
-        (gauge_model.py:256-266) and dQ compares input and output (:718-725)."""
+        (gauge_model.py:256-266) and dQ compares input and output (:718-725).  Runs as ONE library call
+        (l2hmc_gauge_mcmc_step: draws + both trajectories + mix/accept + observables + wrap)."""
+        dyn = self.dynamics
+        if dyn.both_directions:
+            import ctypes as C
+            x_next = x.clone()
+            B = x.shape[0]
+            outs = {k: torch.empty(B, dtype=torch.float32, device=x.device)
+                    for k in ("px", "action", "avg_plaq", "top_charge", "dq")}
+            plan, L = dyn._plan(), _lib.lib()
+            ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
+            _lib.check(L.l2hmc_gauge_mcmc_step(
+                C.byref(plan), float(beta), x_next.data_ptr(), B, dyn._seed, self._step_count, outs["px"].data_ptr(),
+                outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(), outs["top_charge"].data_ptr(),
+                outs["dq"].data_ptr(), ws, nb, _lib.stream_ptr()))
+            self._step_count += 1
+            self.stats.push(outs["px"], outs["dq"])
+            return x_next, outs["px"], outs, outs["dq"]
+        return self._step_composed(x, beta)
+
+    def _step_composed(self, x, beta):
+        """The same step from the separate public ops (used for selected-only mode and as a cross-check)."""
         T, X = self.lattice.time_size, self.lattice.space_size
         _, _, px, x_out = self.dynamics(x, beta)
         obs = u1_observables(x, T, X)

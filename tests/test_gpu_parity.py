@@ -519,6 +519,46 @@ def test_hmc_sampling_reproduces_exact_plaquette(la):
     assert abs(np.mean(plaqs) - exact) < 4e-3, (np.mean(plaqs), exact)
 
 
+@pytest.mark.parametrize("L,arch,B", [(8, "generic", 70), (4, "generic", 9), (8, "conv3D", 21), (16, "generic", 5)])
+def test_native_mcmc_step_matches_oracle_on_its_own_draws(la, L, arch, B):
+    """l2hmc_gauge_mcmc_step (draws + both trajectories + mix/MH + observables + wrap in one call).  Its Philox
+    streams are reproducible through l2hmc_fill_*, so the oracle can be fed the very same draws."""
+    import ctypes as C
+    from l2hmc_amd import _lib
+    N, eps, beta, D = 3, 0.1, 2.0, 2 * L * L
+    xp, vp = (H.conv_weights if arch == "conv3D" else H.gauge_weights)(L, L, regime="mild")
+    orc = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch)
+    dyn = H.gauge_hip(L, L, N, eps, xp, vp, orc.mask, B, arch=arch)
+    x0 = np.random.default_rng(3).uniform(0, 2 * np.pi, (B, D)).astype(np.float32)
+    x = torch.as_tensor(x0, device="cuda").clone()
+    outs = [torch.empty(B, device="cuda") for _ in range(5)]
+    plan, Lh = dyn._plan(), _lib.lib()
+    ws, nb = dyn._ws.get(Lh.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
+    seed, draw = 77, 5
+    _lib.check(Lh.l2hmc_gauge_mcmc_step(C.byref(plan), beta, x.data_ptr(), B, seed, draw, *[o.data_ptr() for o in outs],
+                                         ws, nb, _lib.stream_ptr()))
+    V = torch.empty(2 * B, D, device="cuda")
+    cu = torch.empty(2 * B, device="cuda")
+    _lib.check(Lh.l2hmc_fill_normal(V.data_ptr(), V.numel(), seed, 2 * draw, None))
+    _lib.check(Lh.l2hmc_fill_uniform(cu.data_ptr(), cu.numel(), seed, 2 * draw + 1, None))
+    V, cu = np_(V), np_(cu)
+    x64 = x0.astype(np.float64)
+    want = orc.apply_transition(x64, beta, V[:B], V[B:], cu[:B], cu[B:])
+    px, actions, plaqs, charges, dq = [np_(o) for o in outs]
+    assert np.abs(px - want[2]).max() < TOL_P
+    assert H.relerr(actions, olat.total_action(x64, L, L)) < TOL_OP
+    assert H.relerr(plaqs, olat.avg_plaq(x64, L, L)) < TOL_OP
+    assert H.relerr(charges, olat.top_charge(x64, L, L)) < 1e-4
+    safe = np.abs(want[2] - cu[B:]) > 1e-4
+    assert H.relerr(dq[safe], olat.top_charge_diff(x64, want[3], L, L)[safe]) < 1e-3
+    xw = np.mod(want[3], 2 * np.pi)
+    got = np_(x)
+    d = np.abs(got - xw)[safe]
+    d = np.minimum(d, 2 * np.pi - d)           # a value a hair below 0 wraps to just under 2 pi
+    assert d.max() < 5e-5
+    assert got.min() >= 0 and got.max() < 2 * np.pi + 1e-6
+
+
 def test_device_resident_sampling_loop(la):
     """GaugeSampler.run (gauge_model.py:1304-1460 without files/plots): wrap on the device equals np.mod,
     histories have the reference's shapes, beta annealing follows :1039-1046."""
