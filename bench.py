@@ -162,7 +162,7 @@ def main():
                                  (3, "heads_kernel (S/T/Q + update)", 2.0 * rows * 3 * D * Hd)):
             _lib.check(Lh.l2hmc_profile_begin(cls))
             xs = x
-            for _ in range(min(args.steps, 10)):
+            for _ in range(args.steps):
                 xs = step(xs)
             ms, n = C.c_double(), C.c_int64()
             _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))

@@ -225,6 +225,15 @@ int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, in
                           uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
                           float* charge_diff, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
 
+/* Forward value of the training loss, per chain (gauge_model.py:766-795): terms[b] = std_loss + charge_loss;
+ * the scalar loss is their mean over ALL chains of all ranks.  x, x_prop, z: [B][2*T*X]; px, pz: [B].
+ * metric: 0 'l1', 1 'l2', 2 'cos', 3 'cos2', 4 'cos_diff' (:632-657).  Both auxiliary terms compare z with
+ * x_prop, exactly as the reference writes them.  (The backward pass is a later row of the scope table.) */
+int l2hmc_gauge_loss_terms(const float* x, const float* x_prop, const float* px, const float* z,
+                           const float* pz, int64_t B, int32_t T, int32_t X, int32_t metric,
+                           float loss_scale, float aux_weight, float std_weight, float charge_weight,
+                           float* terms, l2hmc_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Generic integrator on 2-D toy targets (MoG / SCG):
  *   utils/dynamics.py:120-225,255-319; utils/sampler.py:28-59;

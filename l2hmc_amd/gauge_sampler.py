@@ -65,6 +65,37 @@ class GaugeSampler:
         self.stats.push(px, dq)
         return x_next, px, obs, dq
 
+    METRICS = {'l1': 0, 'l2': 1, 'cos': 2, 'cos2': 3, 'cos_diff': 4}
+
+    def calc_loss(self, x, beta, metric='cos_diff', loss_scale=1., z=None, **weights):
+        """gauge_model.py:728-797 `_calc_loss`, forward value: (loss, x_out, px, x_dq).  Two transitions (on x
+        and on the auxiliary z ~ N(0,1)), the per-chain terms in one kernel, and the mean over the chains of
+        ALL ranks through one all-reduce of [sum, count] -- the collective north_star asks for."""
+        if metric not in self.METRICS:        # :653-655
+            raise AttributeError(f"metric={metric}. Expected one of: 'l1', 'l2', 'cos', 'cos2', or 'cos_diff'.")
+        dyn = self.dynamics
+        T, X = self.lattice.time_size, self.lattice.space_size
+        x = _lib.as_dev(x, dyn._device)
+        x_prop, _, px, x_out = dyn(x, beta)
+        z = dyn._normal(tuple(x.shape)) if z is None else _lib.as_dev(z, dyn._device)
+        _, _, pz, _ = dyn(z, beta)
+        terms = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().l2hmc_gauge_loss_terms(
+            x.data_ptr(), x_prop.data_ptr(), px.data_ptr(), z.data_ptr(), pz.data_ptr(), x.shape[0], T, X,
+            self.METRICS[metric], float(loss_scale), float(weights.get('aux_weight', 1.)),
+            float(weights.get('std_weight', 1.)), float(weights.get('charge_weight', 1.)), terms.data_ptr(),
+            _lib.stream_ptr()))
+        buf = torch.stack([terms.sum(dtype=torch.float32),
+                           torch.full((), float(terms.numel()), dtype=torch.float32, device=x.device)])
+        if self.stats.dist is not None:
+            self.stats.dist.all_reduce(buf, op=self.stats.dist.ReduceOp.SUM)
+        loss = buf[0] / buf[1]
+        q0 = u1_observables(x, T, X)["top_charge"]
+        q1 = u1_observables(x_out, T, X)["top_charge"]
+        x_dq = torch.abs(q0 - q1).to(torch.int32)          # :762-763
+        self.last_loss_terms = terms
+        return loss, x_out, px, x_dq
+
     def run(self, run_steps, beta, x=None, keep_samples=False):
         """:1304-1460 without the file/plot side effects.  Starts from N(0,1) samples like the reference
         (:1354) unless `x` is given.  Returns per-step histories as NumPy arrays [steps, B]."""

@@ -559,6 +559,35 @@ def test_native_mcmc_step_matches_oracle_on_its_own_draws(la, L, arch, B):
     assert got.min() >= 0 and got.max() < 2 * np.pi + 1e-6
 
 
+@pytest.mark.parametrize("metric", ["cos_diff", "l2", "cos"])
+def test_loss_forward_matches_oracle(la, metric):
+    """gauge_model.py:728-797 forward value; the kernel gets the oracle's own proposals so only the loss
+    arithmetic is under test, then the end-to-end method is checked for consistency."""
+    from oracle import loss as oloss
+    from l2hmc_amd import _lib
+    T = X = 8
+    B = 24
+    rng = np.random.default_rng(4)
+    x, xp, z = (rng.uniform(0, 2 * np.pi, (B, 128)) for _ in range(3))
+    px, pz = rng.uniform(0.05, 1, B), rng.uniform(0.05, 1, B)
+    want = oloss.calc_loss_terms(x, xp, px, z, pz, T, X, metric=metric, loss_scale=0.7, aux_weight=0.9, std_weight=1.1,
+                                 charge_weight=1.3)
+    dev = [torch.as_tensor(a, dtype=torch.float32, device="cuda").contiguous() for a in (x, xp, px, z, pz)]
+    terms = torch.empty(B, device="cuda")
+    _lib.check(_lib.lib().l2hmc_gauge_loss_terms(*[d.data_ptr() for d in dev], B, T, X,
+                                                 la.GaugeSampler.METRICS[metric], 0.7, 0.9, 1.1, 1.3, terms.data_ptr(),
+                                                 None))
+    assert np.max(np.abs(np_(terms) - want) / np.maximum(1.0, np.abs(want))) < 5e-5
+    if metric == "cos_diff":
+        orc, _, dyn = _pair(T, X, 3, 0.1, B, "mild")
+        smp = la.GaugeSampler(dyn)
+        loss, x_out, pxd, x_dq = smp.calc_loss(x, 2.0, metric=metric, z=z)
+        assert abs(float(loss) - float(smp.last_loss_terms.mean())) < 1e-4 * max(1.0, abs(float(loss)))
+        assert x_out.shape == (B, 128) and x_dq.dtype == torch.int32 and torch.isfinite(loss)
+        with pytest.raises(AttributeError):
+            smp.calc_loss(x, 2.0, metric="bogus")
+
+
 def test_device_resident_sampling_loop(la):
     """GaugeSampler.run (gauge_model.py:1304-1460 without files/plots): wrap on the device equals np.mod,
     histories have the reference's shapes, beta annealing follows :1039-1046."""

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../l2hmc_amd/csrc"
 for NW in 4 8; do
   OUT=../../tools/_diag/w$NW
   mkdir -p $OUT
-  for f in capi u1_lattice stq_dense leapfrog small_mlp fused_traj conv3d_front mcmc_step; do
+  for f in capi u1_lattice stq_dense leapfrog small_mlp fused_traj conv3d_front mcmc_step loss; do
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DL2HMC_STAMPS -DL2HMC_FUSED_WAVES=$NW $EXTRA -c $f.hip -o $OUT/$f.o &
   done
   wait
