@@ -38,22 +38,31 @@ constexpr int kFWaves = L2HMC_FUSED_WAVES;   // waves per workgroup (4 = one per
 constexpr int kFThreads = 64 * kFWaves;   // wave w owns output columns [w*N/kFWaves, (w+1)*N/kFWaves)
 constexpr int kTPC = kFThreads / kFM;     // threads per chain in the chain-local passes
 
-template <int D, int H>
+// D = x_dim, H = hidden width, KA = width of each first-layer input (x_dim for GenericNet; the flattened conv
+// features for ConvNet3D), CONV = the two inputs go through the conv front-end first (8x8 lattice, F = 8).
+template <int D, int H, int KA = D, bool CONV = false>
 struct FusedCfg {
   static constexpr int SX = D + 8;             // LDS row stride of x / v / second-input rows
+  static constexpr int SA = KA + 8;            // LDS row stride of the conv feature rows
   static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
   static constexpr int NT1 = H / (16 * kFWaves);   // 16-column tiles per wave, layers 1 and 2
   static constexpr int NTH = D / (16 * kFWaves);   // tiles per wave per head
   static_assert(NT1 >= 1 && NTH >= 1, "every wave needs at least one tile per layer");
-  static constexpr int KC1 = 2 * D / 16;       // k-chunks (16 k each), layer 1
+  static constexpr int KC1 = 2 * KA / 16;      // k-chunks (16 k each), layer 1
   static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
-  static constexpr size_t P1 = (size_t)2 * D * H;   // packed floats per section
+  static constexpr size_t P1 = (size_t)2 * KA * H;  // packed floats per section
   static constexpr size_t P2 = (size_t)H * H;
   static constexpr size_t PH = (size_t)3 * D * H;
   // per-net constants kept in LDS: b1[H] wt[2H] bh[H] bhd[3D] exp(cs)[D] exp(cq)[D]
   static constexpr int NC = 4 * H + 5 * D;
+  // conv front-end (CONV only): F = 8 filters on the 8x8 lattice
+  static constexpr int CF = 8, CL = 8;
+  static constexpr int CW = 18 * CF + CF + 8 * CF * CF + 2 * CF;            // one (net, input) filter set
+  static constexpr int CXIN = (CL + 2) * (CL + 2) * 2;                      // haloed chain
+  static constexpr int CP1 = (CL / 2 + 1) * (CL / 2 + 1) * CF;              // pooled conv1 map, zero halo
+  static constexpr int CONV_FLOATS = CONV ? 2 * kFM * SA + 4 * CW + kFM * (CXIN + CP1) : 0;
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
-                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/;
+                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/ + CONV_FLOATS;
 };
 
 // exp / tanh on the hardware exp2 + rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Arguments here are
@@ -185,6 +194,7 @@ struct FusedArgs {
   float eps, beta;
   const float* masks;                    // [num_steps][D]
   l2hmc_dense_net xnet, vnet;            // .packed must be set
+  l2hmc_conv3d_front xfront, vfront;     // ConvNet3D only
   const float* x0; const float* v0;      // [rows][D]
   const int* dir;                        // [rows] or NULL
   int64_t x_mod;                         // > 0: row r starts from x0[r % x_mod] (both directions of one batch)
@@ -203,10 +213,10 @@ int g_fused_stagger = 0;
 extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; }
 #endif
 
-template <int D, int H>
+template <int D, int H, int KA, bool CONV>
 __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p) {
-  using Cfg = FusedCfg<D, H>;
-  constexpr int SX = Cfg::SX, SH = Cfg::SH, NT1 = Cfg::NT1, NTH = Cfg::NTH;
+  using Cfg = FusedCfg<D, H, KA, CONV>;
+  constexpr int SX = Cfg::SX, SH = Cfg::SH, SA = Cfg::SA, NT1 = Cfg::NT1, NTH = Cfg::NTH;
   constexpr int sites = D / 2;
   constexpr int SP = sites + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -221,6 +231,12 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   float* skm = sp + kFM * SP;              // [2][D]  masks of this step: forward row, backward row
   float* ldw = skm + 2 * D;                // [waves][16] log-det partial sums per wave
   int* sdir = reinterpret_cast<int*>(ldw + kFWaves * kFM);   // [16]
+  // ConvNet3D front-end state (CONV only; zero-sized otherwise)
+  float* fa = reinterpret_cast<float*>(sdir + kFM);   // [16][SA] features of the first input
+  float* fb = fa + kFM * SA;                          // [16][SA] features of the second input
+  float* cwl = fb + kFM * SA;                         // [net x|v][input a|b][CW] filters
+  float* cxin = cwl + 4 * Cfg::CW;                    // [16][CXIN] haloed chains
+  float* cp1 = cxin + kFM * Cfg::CXIN;                // [16][CP1]  pooled conv1 maps
 
   // diagnostic cycle shares: 0-2 gemm L1/L2/heads, 3-5 their epilogues, 6 barriers, 7 force, 8 mask pass, 9 total
   [[maybe_unused]] unsigned long long ft[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -269,6 +285,23 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   };
   load_consts(p.xnet, cx);
   load_consts(p.vnet, cv);
+  if constexpr (CONV) {
+    constexpr int F = Cfg::CF, F2 = 2 * Cfg::CF;
+    auto load_filters = [&](const float* w1, const float* b1, const float* w2, const float* b2, float* dst) {
+      for (int i = tid; i < 18 * F; i += kFThreads) dst[i] = w1[i];
+      for (int i = tid; i < F; i += kFThreads) dst[18 * F + i] = b1[i];
+      for (int i = tid; i < 4 * F * F2; i += kFThreads) {      // Keras [di][dj][dd][c][g]: keep dd = 0
+        const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
+        dst[19 * F + i] = w2[((size_t)(tap * 2) * F + c) * F2 + g];
+      }
+      for (int i = tid; i < F2; i += kFThreads) dst[19 * F + 4 * F * F2 + i] = b2[i];
+    };
+    load_filters(p.xfront.w1_a, p.xfront.b1_a, p.xfront.w2_a, p.xfront.b2_a, cwl + 0 * Cfg::CW);
+    load_filters(p.xfront.w1_b, p.xfront.b1_b, p.xfront.w2_b, p.xfront.b2_b, cwl + 1 * Cfg::CW);
+    load_filters(p.vfront.w1_a, p.vfront.b1_a, p.vfront.w2_a, p.vfront.b2_a, cwl + 2 * Cfg::CW);
+    load_filters(p.vfront.w1_b, p.vfront.b1_b, p.vfront.w2_b, p.vfront.b2_b, cwl + 3 * Cfg::CW);
+    for (int i = tid; i < kFM * (Cfg::CXIN + Cfg::CP1); i += kFThreads) cxin[i] = 0.f;   // halos stay zero
+  }
   if (tid < kFM) {
     int d = 0;
     if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
@@ -329,6 +362,83 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   // ---- one network evaluation + fused sub-update ------------------------------
   // in1: first input rows (LDS, stride SX); second input is always gs.
   // mode 1: momentum update (uses gs as the force), mode 2: position update with keep masks.
+  // ConvNet3D front-end on a [16][SX] LDS array (network/conv_net.py:251-262; same arithmetic as
+  // conv3d_front_kernel): conv1(3,3,2)+relu+pool -> cp1, conv2(2,2,[2])+relu+pool -> dst [16][SA].
+  [[maybe_unused]] auto conv_features = [&](const float* src, const float* cw, float* dst) {
+    constexpr int F = Cfg::CF, F2 = 2 * Cfg::CF, L = Cfg::CL, LP = L + 2, L2 = L / 2, L2P = L2 + 1, L4 = L / 4;
+    const float* w1 = cw;
+    const float* b1 = cw + 18 * F;
+    const float* w2 = b1 + F;
+    const float* b2 = w2 + 4 * F * F2;
+    for (int i = tid; i < kFM * D; i += kFThreads) {
+      const int c = i / D, e = i - c * D;
+      const int site = e >> 1, mu = e & 1, ii = site / L, jj = site - ii * L;
+      cxin[c * Cfg::CXIN + ((ii + 1) * LP + jj + 1) * 2 + mu] = src[c * SX + e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kFM * L2 * L2 * F; idx += kFThreads) {
+      const int f = idx % F;
+      int rr = idx / F;
+      const int J = rr % L2;
+      rr /= L2;
+      const int I = rr % L2, c = rr / L2;
+      const float bias = b1[f];
+      float m = -INFINITY;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int i = 2 * I + a, j = 2 * J + bb;
+          float v0 = bias, v1 = bias;
+#pragma unroll
+          for (int di = 0; di < 3; ++di) {
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+              const float* px = cxin + c * Cfg::CXIN + ((i + di) * LP + j + dj) * 2;
+              const float x0 = px[0], x1 = px[1];
+              const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
+              v0 += x0 * k0 + x1 * k1;
+              v1 += x1 * k0;
+            }
+          }
+          m = fmaxf(m, fmaxf(v0, v1));
+        }
+      }
+      cp1[c * Cfg::CP1 + (I * L2P + J) * F + f] = fmaxf(m, 0.f);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kFM * L4 * L4 * F2; idx += kFThreads) {
+      const int g = idx % F2;
+      int rr = idx / F2;
+      const int J2 = rr % L4;
+      rr /= L4;
+      const int I2 = rr % L4, c = rr / L4;
+      const float bias = b2[g];
+      float m = -INFINITY;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int i = 2 * I2 + a, j = 2 * J2 + bb;
+          float v = bias;
+#pragma unroll
+          for (int di = 0; di < 2; ++di) {
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+              const float* pp = cp1 + c * Cfg::CP1 + ((i + di) * L2P + j + dj) * F;
+              const float* kk = w2 + ((di * 2 + dj) * F) * F2 + g;
+#pragma unroll
+              for (int ch = 0; ch < F; ++ch) v += pp[ch] * kk[ch * F2];
+            }
+          }
+          m = fmaxf(m, v);
+        }
+      }
+      dst[c * SA + (I2 * L4 + J2) * F2 + g] = fmaxf(m, 0.f);
+    }
+    __syncthreads();
+  };
+
   // First-layer pre-activations that recur unchanged and are kept in registers instead of being recomputed
   // (bit-identical results, 8.3 % fewer weight bytes and MFMAs per leapfrog step):
   //   keep_v: VNet's whole first-layer product.  The second half-kick of step s and the first half-kick of
@@ -340,7 +450,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   // l1: 0 = compute both halves; 1 = as 0 and store the raw product in keep_v; 2 = take keep_v, no GEMM;
   //     3 = compute, snapshot the first-input half into keep_x; 4 = start from keep_x, second half only.
   auto net_update = [&](const l2hmc_dense_net& net, const float* cn, const float* in1, int mode, int sub,
-                        bool prep_next_mask, int l1, const float (&tcr)[4], const float (&tsr)[4]) {
+                        bool prep_next_mask, int l1, bool is_vnet, const float (&tcr)[4],
+                        const float (&tsr)[4]) {
     const float* pk = net.packed;
     const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
     const float* wp2 = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
@@ -352,6 +463,18 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       constexpr int KH = Cfg::KC1 / 2;
       f32x4 acc[NT1];
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
+      // inputs of the dense trunk: the LDS rows themselves, or their conv features
+      const float* src1 = in1;
+      const float* src2 = gs;
+      int s1 = SX;
+      if constexpr (CONV) {
+        const float* cwn = cwl + (is_vnet ? 2 : 0) * Cfg::CW;
+        if (l1 == 0 || l1 == 1 || l1 == 3) conv_features(in1, cwn, fa);            // first input (conv_v*)
+        if (l1 != 2) conv_features(gs, cwn + Cfg::CW, fb);                          // second input (conv_x*)
+        src1 = fa;
+        src2 = fb;
+        s1 = SA;
+      }
       if (l1 == 2) {
 #pragma unroll
         for (int t = 0; t < NT1; ++t) acc[t] = keep_v[t];
@@ -366,7 +489,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
           ring_prime<NT1>(RA, wp1);
 #pragma unroll
           for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* a1 = in1 + r * SX + q * 4;
+          const float* a1 = src1 + r * s1 + q * 4;
           stream_layer<NT1, KH>(
               RA, wp1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a1 + kc * 16); }, acc);
           ring_prime<NT1>(RB, wpb);
@@ -375,7 +498,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
             for (int t = 0; t < NT1; ++t) keep_x[t] = acc[t];
           }
         }
-        const float* a2 = gs + r * SX + q * 4;
+        const float* a2 = src2 + r * s1 + q * 4;
         stream_layer<NT1, KH>(
             RB, wpb, [&](int kc) { return *reinterpret_cast<const f32x4*>(a2 + kc * 16); }, acc);
         if (l1 == 1) {
@@ -536,7 +659,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       // call 2: position sub-update 2                          call 3: second momentum half-kick (product kept)
       const int l1 = call == 0 ? (keep_v_valid ? 2 : 0) : call == 1 ? 3 : call == 2 ? 4 : 1;
       net_update(is_v ? p.vnet : p.xnet, is_v ? cv : cx, is_v ? xs : vs, is_v ? 1 : 2, call == 2 ? 1 : 0,
-                 call < 2, l1, tcr, tsr);
+                 call < 2, l1, is_v, tcr, tsr);
     }
     keep_v_valid = true;
   }
@@ -579,25 +702,40 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int fused_net_supported(const l2hmc_dense_net* n) {
+// shapes with a whole-trajectory kernel: GenericNet on D=128 (H=512), and the dense trunk of ConvNet3D on the
+// 8x8 lattice (features 64+64, H=256)
+static int fused_generic_net(const l2hmc_dense_net* n) {
   return n->D == 128 && n->H == 512 && n->Ka == 128 && n->Kb == 128;
 }
+static int fused_conv_net(const l2hmc_dense_net* n) {
+  return n->D == 128 && n->H == 256 && n->Ka == 64 && n->Kb == 64;
+}
+int fused_net_supported(const l2hmc_dense_net* n) { return fused_generic_net(n) || fused_conv_net(n); }
 
 int fused_plan_supported(const l2hmc_gauge_plan* p) {
-  return !p->hmc && fused_net_supported(&p->xnet) && fused_net_supported(&p->vnet) && p->xnet.packed &&
-         p->vnet.packed && 2 * p->T * p->X == 128;
+  if (p->hmc || !p->xnet.packed || !p->vnet.packed || 2 * p->T * p->X != 128) return 0;
+  if (p->flags & L2HMC_PLAN_CONV3D)
+    return fused_conv_net(&p->xnet) && fused_conv_net(&p->vnet) && p->T == 8 && p->X == 8 && p->xfront.F == 8 &&
+           p->vfront.F == 8;
+  return fused_generic_net(&p->xnet) && fused_generic_net(&p->vnet);
 }
 
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
                             float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
                             hipStream_t stream, int64_t x_mod, int64_t dir_split) {
-  using Cfg = FusedCfg<128, 512>;
+  const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
+  using CfgG = FusedCfg<128, 512, 128, false>;
+  using CfgC = FusedCfg<128, 256, 64, true>;
   static bool attr_set = false;
-  const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : CfgG::LDS_FLOATS);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 256, 64, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * CfgC::LDS_FLOATS)) != hipSuccess) {
       set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
       return L2HMC_ERR_HIP;
     }
@@ -606,6 +744,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   FusedArgs a{};
   a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = step_begin; a.step_end = step_end;
   a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
+  a.xfront = p->xfront; a.vfront = p->vfront;
   a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
   a.x_mod = x_mod; a.dir_split = dir_split;
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
@@ -615,7 +754,10 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
 #endif
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
-  hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512>), grid, dim3(kFThreads), lds, stream, a);
+  if (conv)
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(kFThreads), lds, stream, a);
+  else
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(kFThreads), lds, stream, a);
   prof_after(kProfFused, stream);
   L2HMC_CHECK_LAUNCH("gauge_traj_fused");
   return L2HMC_OK;

@@ -186,7 +186,7 @@ struct GaugeWs {
 };
 
 static bool use_fused(const l2hmc_gauge_plan* p) {
-  return !(p->flags & (L2HMC_PLAN_LAYERED | L2HMC_PLAN_CONV3D)) && fused_plan_supported(p);
+  return !(p->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(p);
 }
 static int gauge_hmax(const l2hmc_gauge_plan* p) { return p->hmc ? 0 : hmax(p->xnet.H, p->vnet.H); }
 static int gauge_ncb(const l2hmc_gauge_plan* p) { return (int)ceil_div(2 * p->T * p->X, 32); }

@@ -170,7 +170,7 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
                      (int64_t)2 * B * D, cu, 2 * B, seed, draw);
   L2HMC_CHECK_LAUNCH("step_draws");
 
-  const bool fused = !(plan->flags & (L2HMC_PLAN_LAYERED | L2HMC_PLAN_CONV3D)) && fused_plan_supported(plan);
+  const bool fused = !(plan->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(plan);
   const bool fast_finish = sites % kWave == 0 && 256 % sites == 0;
   if (fused && fast_finish) {
     if (int e = launch_fused_trajectory(plan, beta, 0, plan->num_steps, x, Vw, nullptr, 2 * B, Xw, Vw, nullptr, 0, Pw,

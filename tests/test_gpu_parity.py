@@ -328,12 +328,13 @@ def test_conv3d_dynamics_matches_oracle(la, L, N, B, regime):
     want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
     f32 = orc32.apply_transition(x.astype(np.float32), beta, v0f.astype(np.float32), v0b.astype(np.float32), coin,
                                  u.astype(np.float32))
-    for both in (True, False):
-        dyn.both_directions = both
+    for both, fused in ((True, True), (False, True), (True, False)):      # fused whole-trajectory kernel at L=8
+        dyn.both_directions, dyn.fused = both, fused
         got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
         assert_fp32_equivalent(got[0], want[0], f32[0], "x_prop")
         assert_fp32_equivalent(got[1], want[1], f32[1], "v_prop")
         assert np.abs(got[2] - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+    dyn.fused = True
 
 
 # ----------------------------------------------------------------- golden fixtures
