@@ -149,7 +149,8 @@ def main():
     history.clear()
 
     # ---- roofline of the dominant kernel, HIP events on the launch stream ----
-    if rank == 0 and not args.no_roofline:
+    # (every rank runs the profiled steps -- they contain the per-step collective -- only rank 0 reports)
+    if not args.no_roofline:
         Lh = _lib.lib()
         rows = (2 if both else 1) * BATCH
         Hd = HID_MULT * D
@@ -169,6 +170,7 @@ def main():
             per_class[cls] = dict(kernel=name, launches=n.value, avg_us=1e3 * ms.value / max(n.value, 1),
                                   flops_per_launch=flops,
                                   tflops=flops / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0)
+        stats.wait()
         per_class = {k: v for k, v in per_class.items() if v["launches"]}
         dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
         out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
@@ -178,6 +180,24 @@ def main():
                            "all_kernels": list(per_class.values()),
                            "whole_step_tflops": (2 if both else 1) * BATCH * N_LF * 8 * net_macs(D, Hd)
                            / (dt / args.steps) / 1e12}
+
+    # ---- the same workload with the reference's CLI-default architecture (conv3D, gauge_model.py:2307) ----
+    if rank == 0 and world == 1 and not args.no_roofline:
+        from tests import helpers as H
+        cxp, cvp = H.conv_weights(L, L, seed=106, regime="init")
+        cdyn = H.gauge_hip(L, L, N_LF, EPS, cxp, cvp, masks, BATCH, both_directions=both, arch='conv3D')
+        csmp = GaugeSampler(cdyn)
+        xc = x.clone()
+        for _ in range(3):
+            xc = csmp.step(xc, BETA)[0]
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for _ in range(20):
+            xc = csmp.step(xc, BETA)[0]
+        torch.cuda.synchronize()
+        tcd = (time.perf_counter() - tc0) / 20
+        out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
+                                        "chain_leapfrog_steps_per_s": BATCH * N_LF / tcd}
 
     # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

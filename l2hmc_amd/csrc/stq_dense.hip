@@ -29,7 +29,7 @@ namespace l2hmc {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;            // k-tile
+constexpr int BK = 32;            // k-tile granularity every width must be a multiple of
 constexpr int kGemmThreads = 256;  // 4 waves
 
 // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD, give each XCD a
@@ -48,10 +48,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // KIND 1: first layer (two k-contiguous sources, optional column mask, time term)
 // KIND 2: hidden layer (single source, plain bias)
-template <int BM, int KIND>
+template <int BM, int KIND, int BK>
 __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int BN = 128;
-  constexpr int LDK = BK + 4;              // 36 floats = 144 B rows: conflict-free b128 reads
+  constexpr int CPR = BK / 4;              // 16-byte chunks per staged row
+  constexpr int LDK = BK + 4;              // rows of 36 / 68 floats: an odd number of 16-B slots => conflict-free b128 reads
   constexpr int MT = BM / 64;              // 32x32 tiles per wave along M (wave grid 2 x 2)
   constexpr int NT = 2;                    // wave covers 64 columns
   constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    a_row[i] = c >> 3;
-    a_kc[i] = (c & 7) * 4;
+    a_row[i] = c / CPR;
+    a_kc[i] = (c % CPR) * 4;
     a_ok[i] = (m0 + a_row[i]) < p.rows;
     a_dir[i] = (KIND == 1 && p.dir && a_ok[i]) ? p.dir[m0 + a_row[i]] : 0;
   }
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    b_row[i] = c >> 3;
-    b_kc[i] = (c & 7) * 4;
+    b_row[i] = c / CPR;
+    b_kc[i] = (c % CPR) * 4;
     b_ok[i] = (n0 + b_row[i]) < p.N;
   }
 
@@ -207,11 +208,13 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 // =====================================================================
 
 
+template <int BK>
 __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   constexpr int BM = 64, BNH = 32, NB = 3 * BNH;
-  constexpr int LDK = BK + 8;             // 40 floats: conflict-free for the 16-row fragment reads
-  constexpr int A_CH = BM * (BK / 4) / kGemmThreads;   // 2
-  constexpr int B_CH = NB * (BK / 4) / kGemmThreads;   // 3
+  constexpr int CPR = BK / 4;
+  constexpr int LDK = BK + 8;             // 40 / 72 floats (= 8 mod 64): conflict-free for the 16-row fragment reads
+  constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
+  constexpr int B_CH = NB * (BK / 4) / kGemmThreads;
   constexpr int STAGE = (BM + NB) * LDK;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    a_row[i] = c >> 3;
-    a_kc[i] = (c & 7) * 4;
+    a_row[i] = c / CPR;
+    a_kc[i] = (c % CPR) * 4;
     a_ok[i] = (m0 + a_row[i]) < p.rows;
   }
   int b_row[B_CH], b_kc[B_CH];
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    b_row[i] = c >> 3;                      // 0..95 = head * 32 + nn
-    b_kc[i] = (c & 7) * 4;
+    b_row[i] = c / CPR;                     // 0..95 = head * 32 + nn
+    b_kc[i] = (c % CPR) * 4;
     const int hd = b_row[i] >> 5, nn = b_row[i] & 31;
     b_ok[i] = (n0 + nn) < p.D;
     b_src[i] = ((int64_t)hd * p.D + n0 + nn) * p.K;
@@ -428,16 +431,25 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   const bool first = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr;
   const int cls = first ? kProfGemmL1 : kProfGemmL2;
   prof_before(cls, stream);
+  // 64-deep k-tiles halve the number of barriers (K ranges must be multiples of 64); their 102 KB of LDS allow one
+  // workgroup per CU, so they are used when the grid has at most one workgroup per CU anyway -- larger grids
+  // keep 32-deep tiles and two co-resident workgroups that hide each other's stalls
+  const bool deep = (a.K % 64 == 0) && (a.K1 % 64 == 0) && ceil_div(a.rows, 64) * a.ntiles <= 256;
   if (t128 >= 512) {
     a.mtiles = (int)ceil_div(a.rows, 128);
     const dim3 grid(a.mtiles * a.ntiles);
-    if (first) hipLaunchKernelGGL((gemm_relu_kernel<128, 1>), grid, dim3(kGemmThreads), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_relu_kernel<128, 2>), grid, dim3(kGemmThreads), 0, stream, a);
+    if (first) hipLaunchKernelGGL((gemm_relu_kernel<128, 1, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_relu_kernel<128, 2, 32>), grid, dim3(kGemmThreads), 0, stream, a);
   } else {
     a.mtiles = (int)ceil_div(a.rows, 64);
     const dim3 grid(a.mtiles * a.ntiles);
-    if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1>), grid, dim3(kGemmThreads), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_relu_kernel<64, 2>), grid, dim3(kGemmThreads), 0, stream, a);
+    if (deep) {
+      if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 64>), grid, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 64>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else {
+      if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+    }
   }
   prof_after(cls, stream);
   L2HMC_CHECK_LAUNCH("gemm_relu");
@@ -455,7 +467,10 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
   a.ntiles = (int)ceil_div(a.D, 32);
   L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
   prof_before(kProfHeads, stream);
-  hipLaunchKernelGGL(heads_kernel, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  if (a.K % 64 == 0 && a.mtiles * a.ntiles <= 256)
+    hipLaunchKernelGGL(heads_kernel<64>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(heads_kernel<32>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
   prof_after(kProfHeads, stream);
   L2HMC_CHECK_LAUNCH("heads");
   return L2HMC_OK;

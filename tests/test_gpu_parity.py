@@ -146,6 +146,7 @@ def _pair(T, X, N, eps, B, regime, fused=True, hmc=False, both=True):
 
 
 CASES = [  # T, X, N, eps, beta, B, regime, fused
+    (8, 8, 2, 0.25, 2.0, 1, "stress", True),      # a single chain (15 of the workgroup's 16 rows are padding)
     (8, 8, 10, 0.25, 2.0, 71, "init", True),      # cfg-3 shape, whole-trajectory kernel, ragged batch
     (8, 8, 10, 0.25, 2.0, 71, "init", False),     # same through the layer-by-layer kernels
     (8, 8, 10, 0.25, 2.0, 33, "mild", True),
@@ -203,7 +204,7 @@ def test_trajectory_within_1e5_on_benign_dynamics(la):
         assert want[2].mean() > 0.05       # a regime where proposals actually get accepted
 
 
-@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES[:6])
+@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES[:7])
 def test_apply_transition_matches_oracle_in_both_modes(la, T, X, N, eps, beta, B, regime, fused):
     orc, orc32, dyn = _pair(T, X, N, eps, B, regime, fused)
     x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * T * X)
@@ -602,6 +603,12 @@ def test_device_resident_sampling_loop(la):
     w = smp.wrap(xs)
     np.testing.assert_allclose(np_(w), np.mod(xs.cpu().numpy(), np.float32(2 * np.pi)), atol=2e-6)
     assert float(w.min()) >= 0 and float(w.max()) < 2 * np.pi + 1e-6
+    # selected-only mode goes through the separate public ops and must give the same kind of step
+    dyn.both_directions = False
+    xa, pxa, obsa, dqa = smp.step(w.clone(), 2.0)
+    assert xa.shape == w.shape and float(xa.min()) >= 0 and torch.all((pxa >= 0) & (pxa <= 1))
+    assert H.relerr(np_(obsa["action"]), olat.total_action(np_(w), T, X)) < TOL_OP
+    dyn.both_directions = True
     out = smp.run(5, 2.0, keep_samples=True)
     assert out["px"].shape == (5, B) and out["samples"].shape == (5, B, 128)
     assert np.all((out["px"] >= 0) & (out["px"] <= 1)) and abs(out["plaq_exact"] - 0.697775) < 1e-6

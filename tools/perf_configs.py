@@ -79,6 +79,12 @@ def u1_roofline():
 
 def main():
     print("device", torch.cuda.get_device_name(0), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
+        gauge("cfg4 U(1) 16x16 conv3D, B=1024/GPU, 15 LF", 16, 1024, 15, 0.2, 3.0, 'conv3D', iters=3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4g":
+        gauge("cfg4-like U(1) 16x16 generic, B=1024/GPU, 15 LF", 16, 1024, 15, 0.2, 3.0, 'generic', iters=3)
+        return
     u1_roofline()
     small("cfg1 SCG 2-D, B=128, 5 LF, H=10",
           la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]])), 128, 5, 10)
