@@ -17,10 +17,11 @@
 
 namespace l2hmc {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kConvThreads = 256;
 
 __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArgs p) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;                   // 0: first input, 1: second input
   const int T = p.T, X = p.X, F = p.F, F2 = 2 * p.F;
   const int D = 2 * T * X;
@@ -110,25 +111,31 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
     r /= X4;
     const int I2 = r % T4, c = r / T4;
     const float bias = b2[g];
-    float m = -INFINITY;
+    // 2x2 outputs of the pooling window share a 3x3 patch of the pooled conv1 map: per 4 input channels,
+    // 9 ds_read_b128 (patch, broadcast across the g lanes) + 16 weight reads feed 64 FMAs
+    float acc[2][2] = {{bias, bias}, {bias, bias}};
+    const float* pbase = p1 + ((c * T2P + 2 * I2) * X2P + 2 * J2) * F;
+    for (int ch4 = 0; ch4 < F; ch4 += 4) {
+      f32x4 w[3][3];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+      for (int wi = 0; wi < 3; ++wi)
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int i = 2 * I2 + a, j = 2 * J2 + bb;
-        float v = bias;
+        for (int wj = 0; wj < 3; ++wj)
+          w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * X2P + wj) * F + ch4);
 #pragma unroll
-        for (int di = 0; di < 2; ++di) {
+      for (int di = 0; di < 2; ++di)
 #pragma unroll
-          for (int dj = 0; dj < 2; ++dj) {
-            const float* pp = p1 + ((c * T2P + i + di) * X2P + j + dj) * F;   // zero halo beyond the edge
-            const float* kk = w2 + ((di * 2 + dj) * F) * F2 + g;
-            for (int ch = 0; ch < F; ++ch) v += pp[ch] * kk[ch * F2];
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float kw = w2[((di * 2 + dj) * F + ch4 + cc) * F2 + g];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) acc[a][bb] += w[a + di][bb + dj][cc] * kw;
           }
-        }
-        m = fmaxf(m, v);
-      }
     }
+    const float m = fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[1][0], acc[1][1]));
     out[(row0 + c) * p.ldo + (I2 * X4 + J2) * F2 + g] = fmaxf(m, 0.f);
   }
 }
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
 int conv3d_nflat(int T, int X, int F) { return (T / 4) * (X / 4) * 2 * F; }
 
 int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
-  L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0, "conv3d front-end: T=%d X=%d must be multiples of 4", a.T,
-                a.X);
+  L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
+                "conv3d front-end: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
   a.cpw = per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
   const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +

@@ -414,26 +414,31 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       rr /= L4;
       const int I2 = rr % L4, c = rr / L4;
       const float bias = b2[g];
-      float m = -INFINITY;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int i = 2 * I2 + a, j = 2 * J2 + bb;
-          float v = bias;
-#pragma unroll
-          for (int di = 0; di < 2; ++di) {
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj) {
-              const float* pp = cp1 + c * Cfg::CP1 + ((i + di) * L2P + j + dj) * F;
-              const float* kk = w2 + ((di * 2 + dj) * F) * F2 + g;
-#pragma unroll
-              for (int ch = 0; ch < F; ++ch) v += pp[ch] * kk[ch * F2];
+      // 2x2 outputs of the pooling window share a 3x3 patch of the pooled conv1 map: per 4 input channels,
+      // 9 ds_read_b128 (patch, broadcast across the g lanes) + 16 weight reads feed 64 FMAs
+      float acc[2][2] = {{bias, bias}, {bias, bias}};
+      const float* pbase = cp1 + c * Cfg::CP1 + ((2 * I2) * L2P + 2 * J2) * F;
+      for (int ch4 = 0; ch4 < F; ch4 += 4) {
+        f32x4 w[3][3];
+  #pragma unroll
+        for (int wi = 0; wi < 3; ++wi)
+  #pragma unroll
+          for (int wj = 0; wj < 3; ++wj)
+            w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * L2P + wj) * F + ch4);
+  #pragma unroll
+        for (int di = 0; di < 2; ++di)
+  #pragma unroll
+          for (int dj = 0; dj < 2; ++dj)
+  #pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float kw = w2[((di * 2 + dj) * F + ch4 + cc) * F2 + g];
+  #pragma unroll
+              for (int a = 0; a < 2; ++a)
+  #pragma unroll
+                for (int bb = 0; bb < 2; ++bb) acc[a][bb] += w[a + di][bb + dj][cc] * kw;
             }
-          }
-          m = fmaxf(m, v);
-        }
       }
+      const float m = fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[1][0], acc[1][1]));
       dst[c * SA + (I2 * L4 + J2) * F2 + g] = fmaxf(m, 0.f);
     }
     __syncthreads();

@@ -118,6 +118,26 @@ class Dynamics(object):
             X.data_ptr(), V.data_ptr(), lj.data_ptr(), p.data_ptr(), _lib.stream_ptr()))
         return (X, V, lj) if log_jac else (X, V, p)
 
+    def both(self, x, init_v_forward=None, init_v_backward=None, log_jac=False):
+        """forward(x) and backward(x) of the same chains in ONE launch (rows stacked, per-row direction):
+        what `propose` needs (sampler.py:38-39).  Returns ((Xf, Vf, pf), (Xb, Vb, pb))."""
+        x = _lib.as_dev(x, self._device).reshape(-1, self.x_dim)
+        B = x.shape[0]
+        vf = _lib.as_dev(init_v_forward, self._device) if init_v_forward is not None else self._normal(tuple(x.shape))
+        vb = _lib.as_dev(init_v_backward, self._device) if init_v_backward is not None else self._normal(tuple(x.shape))
+        xx, vv = torch.cat([x, x]), torch.cat([vf, vb])
+        dirs = torch.cat([torch.zeros(B, dtype=torch.int32, device=x.device),
+                          torch.ones(B, dtype=torch.int32, device=x.device)])
+        X, V = torch.empty_like(xx), torch.empty_like(xx)
+        lj = torch.empty(2 * B, dtype=torch.float32, device=x.device)
+        p = torch.empty_like(lj)
+        plan = self._plan()
+        _lib.check(_lib.lib().l2hmc_small_trajectory(
+            C.byref(plan), xx.data_ptr(), vv.data_ptr(), dirs.data_ptr(), 2 * B, X.data_ptr(), V.data_ptr(),
+            lj.data_ptr(), p.data_ptr(), _lib.stream_ptr()))
+        third = lj if log_jac else p
+        return (X[:B], V[:B], third[:B]), (X[B:], V[B:], third[B:])
+
     def forward(self, x, init_v=None, aux=None, log_path=False, log_jac=False):
         """:255-281."""
         if aux is not None:

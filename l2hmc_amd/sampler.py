@@ -41,8 +41,9 @@ def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False,
     else:
         mask = _lib.as_dev(dir_bits, dynamics._device)
     vb = init_v_backward if init_v_backward is not None else init_v
-    Lx1, Lv1, px1 = dynamics.forward(x, init_v=init_v, aux=aux, log_jac=log_jac)
-    Lx2, Lv2, px2 = dynamics.backward(x, init_v=vb, aux=aux, log_jac=log_jac)
+    if aux is not None:
+        raise NotImplementedError("aux inputs are only used by the out-of-scope VAE scripts")
+    (Lx1, Lv1, px1), (Lx2, Lv2, px2) = dynamics.both(x, init_v, vb, log_jac=log_jac)   # one launch, both directions
     Lx, Lvm, px = torch.empty_like(x), torch.empty_like(x), torch.empty_like(px1)
     out = torch.empty_like(x) if do_mh_step else None
     if do_mh_step and u is None:

@@ -150,6 +150,7 @@ CASES = [  # T, X, N, eps, beta, B, regime, fused
     (8, 8, 10, 0.25, 2.0, 71, "init", True),      # cfg-3 shape, whole-trajectory kernel, ragged batch
     (8, 8, 10, 0.25, 2.0, 71, "init", False),     # same through the layer-by-layer kernels
     (8, 8, 10, 0.25, 2.0, 33, "mild", True),
+    (4, 16, 4, 0.2, 2.0, 19, "mild", True),       # non-square lattice with x_dim 128: still the fused kernel
     (8, 8, 3, 0.2, 2.5, 16, "stress", True),
     (8, 8, 3, 0.2, 2.5, 17, "stress", False),
     (4, 4, 3, 0.2, 2.5, 10, "stress", True),      # D=32: no fused kernel for this shape -> layered path
@@ -204,7 +205,7 @@ def test_trajectory_within_1e5_on_benign_dynamics(la):
         assert want[2].mean() > 0.05       # a regime where proposals actually get accepted
 
 
-@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES[:7])
+@pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES[:8])
 def test_apply_transition_matches_oracle_in_both_modes(la, T, X, N, eps, beta, B, regime, fused):
     orc, orc32, dyn = _pair(T, X, N, eps, B, regime, fused)
     x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * T * X)
