@@ -506,6 +506,7 @@ def test_hmc_sampling_reproduces_exact_plaquette(la):
     (lattice.py:31-33, gauge_model.py:1149,1216).  Plain-HMC mode (gauge_dynamics.py:102-108) through the
     whole device-side MCMC step -- Philox draws, both directions, mixing, MH -- must reproduce it."""
     beta, L, B = 2.0, 8, 1024
+    torch.manual_seed(0)
     lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=B, rand=False)
     dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.12, hmc=True, num_steps=8, eps_trainable=False,
                            network_arch='generic', seed=5)
@@ -630,6 +631,7 @@ def test_full_size_properties_cfg3(la):
     xp, vp = H.gauge_weights(T, X, regime="mild")
     masks = H.gauge_oracle(T, X, N, eps, xp, vp).mask
     dyn = H.gauge_hip(T, X, N, eps, xp, vp, masks, B)
+    torch.manual_seed(1)
     x = torch.rand(B, 128, device="cuda") * (2 * np.pi)
     v = torch.randn(B, 128, device="cuda")
     # (1) reversibility: backward trajectory undoes the forward one, log-dets cancel

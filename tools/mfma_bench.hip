@@ -11,7 +11,7 @@
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int NT = 8;
 
-template <int VARIANT, int WAVES>
+template <int VARIANT, int WAVES, int LOADKIND = 0>
 __global__ __launch_bounds__(64 * WAVES) void bench(const float* __restrict__ w, float* out, int nkc, int iters,
                                                     unsigned long long* cyc) {
   __shared__ __attribute__((aligned(16))) float lds[16 * 520];
@@ -23,26 +23,50 @@ __global__ __launch_bounds__(64 * WAVES) void bench(const float* __restrict__ w,
   const float* wp = w + (size_t)wave * nkc * NT * 256 + lane * 4;
   const float* ap = lds + (lane & 15) * 520 + (lane >> 4) * 4;
   f32x4 b[3][NT];
+  auto ldw = [&](const float* ptr) -> f32x4 {
+    if (LOADKIND == 1) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr));
+    return *reinterpret_cast<const f32x4*>(ptr);
+  };
   f32x4 a = {1.f, 0.5f, 0.25f, 0.125f};
   for (int t = 0; t < NT; ++t) b[0][t] = b[1][t] = b[2][t] = f32x4{0.1f * t, 0.2f, 0.3f, 0.4f};
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
     if (VARIANT >= 1) {
-      for (int t = 0; t < NT; ++t) b[0][t] = *(const f32x4*)(wp + (0 * NT + t) * 256);
-      for (int t = 0; t < NT; ++t) b[1][t] = *(const f32x4*)(wp + (1 * NT + t) * 256);
-      for (int t = 0; t < NT; ++t) b[2][t] = *(const f32x4*)(wp + (2 * NT + t) * 256);
+      for (int t = 0; t < NT; ++t) b[0][t] = ldw(wp + (0 * NT + t) * 256);
+      for (int t = 0; t < NT; ++t) b[1][t] = ldw(wp + (1 * NT + t) * 256);
+      for (int t = 0; t < NT; ++t) b[2][t] = ldw(wp + (2 * NT + t) * 256);
     }
 #pragma nounroll
     for (int kc = 0; kc + 3 <= nkc; kc += 3) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        if (VARIANT >= 2) a = *(const f32x4*)(ap + ((kc + s) & 31) * 16);
+        if (VARIANT == 2) a = *(const f32x4*)(ap + ((kc + s) & 31) * 16);
+        if (VARIANT == 3) {
+          const f32x4 an = *(const f32x4*)(ap + ((kc + s + 1) & 31) * 16);   // next block's A fragment, in flight early
+          // loads for chunk kc+s+3 interleaved 1:1 with the last row of MFMAs: their issue cost hides in the MFMA shadow
+          const bool more = kc + s + 3 < nkc;
+          const float* src = wp + (size_t)(more ? kc + s + 3 : kc + s) * NT * 256;
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[s][t][e], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[s][t][3], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            b[s][t] = ldw(src + t * 256);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          a = an;
+        } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[s][t][e], acc[t], 0, 0, 0);
         if (VARIANT >= 1 && kc + s + 3 < nkc)
-          for (int t = 0; t < NT; ++t) b[s][t] = *(const f32x4*)(wp + ((size_t)(kc + s + 3) * NT + t) * 256);
+          for (int t = 0; t < NT; ++t) b[s][t] = ldw(wp + ((size_t)(kc + s + 3) * NT + t) * 256);
+        }
       }
     }
   }
@@ -53,14 +77,14 @@ __global__ __launch_bounds__(64 * WAVES) void bench(const float* __restrict__ w,
   if (lane == 0) cyc[blockIdx.x * WAVES + wave] = t1 - t0;
 }
 
-template <int V, int W>
+template <int V, int W, int LK = 0>
 void run(const char* name, const float* w, float* out, unsigned long long* cyc, int nkc, int iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  bench<V, W><<<256, 64 * W>>>(w, out, nkc, 2, cyc);
+  bench<V, W, LK><<<256, 64 * W>>>(w, out, nkc, 2, cyc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  bench<V, W><<<256, 64 * W>>>(w, out, nkc, iters, cyc);
+  bench<V, W, LK><<<256, 64 * W>>>(w, out, nkc, iters, cyc);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -84,6 +108,10 @@ int main() {
   run<0, 4>("MFMA only", w, out, cyc, nkc, iters);
   run<1, 4>("MFMA + B stream from L2 (ring 3)", w, out, cyc, nkc, iters);
   run<2, 4>("MFMA + B stream + A from LDS", w, out, cyc, nkc, iters);
+  run<1, 4, 1>("MFMA + B stream, nontemporal loads", w, out, cyc, nkc, iters);
+  run<2, 4, 1>("MFMA + B stream nt + A from LDS", w, out, cyc, nkc, iters);
+  run<3, 4, 0>("MFMA + B stream + A LDS, loads interleaved", w, out, cyc, nkc, iters);
+  run<3, 4, 1>("MFMA + B stream nt + A LDS, interleaved", w, out, cyc, nkc, iters);
   run<0, 8>("MFMA only", w, out, cyc, nkc, iters);
   run<1, 8>("MFMA + B stream from L2 (ring 3)", w, out, cyc, nkc, iters);
   run<2, 8>("MFMA + B stream + A from LDS", w, out, cyc, nkc, iters);
