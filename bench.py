@@ -175,7 +175,7 @@ def main():
         dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
         # fabric-side bytes per launch of the fused kernel at this exact shape, from the committed PMC passes
         # (profiles/r01_pmc_fused_kernel.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction); null otherwise
-        traffic = 315824302 if (dom["kernel"].startswith("gauge_traj_fused") and both) else None
+        traffic = 315824250 if (dom["kernel"].startswith("gauge_traj_fused") and both) else None
         out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes per launch (rocprofv3 --pmc, see profiles/r01_pmc_fused_kernel.json)",
