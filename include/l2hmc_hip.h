@@ -228,11 +228,68 @@ int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, in
 /* Forward value of the training loss, per chain (gauge_model.py:766-795): terms[b] = std_loss + charge_loss;
  * the scalar loss is their mean over ALL chains of all ranks.  x, x_prop, z: [B][2*T*X]; px, pz: [B].
  * metric: 0 'l1', 1 'l2', 2 'cos', 3 'cos2', 4 'cos_diff' (:632-657).  Both auxiliary terms compare z with
- * x_prop, exactly as the reference writes them.  (The backward pass is a later row of the scope table.) */
+ * x_prop, exactly as the reference writes them. */
 int l2hmc_gauge_loss_terms(const float* x, const float* x_prop, const float* px, const float* z,
                            const float* pz, int64_t B, int32_t T, int32_t X, int32_t metric,
                            float loss_scale, float aux_weight, float std_weight, float charge_weight,
                            float* terms, l2hmc_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Training: gradients of the loss with respect to the network weights and the step size, and the
+ * optimiser step -- tf.gradients(loss, dynamics.variables) + AdamOptimizer.apply_gradients of
+ * gauge_model.py:799-830, :942-969.  GenericNet plans only (flags without L2HMC_PLAN_CONV3D, hmc = 0).
+ *
+ * Chains are integrated in the direction their coin selects (rows = x chains then z chains for the
+ * loss of gauge_model.py:728-797; the masked-out direction carries exactly zero gradient in the
+ * reference's graph).  The sequence for one training step is
+ *   l2hmc_gauge_train_forward   -> x_N, v_N, sumlogdet, p        (keeps every intermediate in `ws`)
+ *   l2hmc_gauge_loss_backward   -> per-chain loss, d loss / d (x_N, v_N, sumlogdet)
+ *   l2hmc_gauge_train_backward  -> gradients (same k-contiguous layout as struct l2hmc_dense_net)
+ *   [all-reduce of the flat gradient buffers across ranks]
+ *   l2hmc_grad_sumsq / l2hmc_adam_step
+ * ------------------------------------------------------------------------ */
+typedef struct l2hmc_dense_grads {
+  float* w1_t;     /* [H][Ka+Kb] */
+  float* wt;       /* [2][H]  */
+  float* b1;       /* [H]: gradient of EACH of the three first-layer biases (they are summed in b1) */
+  float* wh_t;     /* [H][H]  */
+  float* bh;       /* [H]     */
+  float* whd_t;    /* [3][D][H] */
+  float* bhd;      /* [3][D]  */
+  float* coeff_s;  /* [D]     */
+  float* coeff_q;  /* [D]     */
+} l2hmc_dense_grads;
+
+size_t l2hmc_gauge_train_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);
+/* Same outputs as l2hmc_gauge_trajectory (dir: per-row 0 forward / 1 backward, NULL = all forward);
+ * `ws` must stay untouched until the matching l2hmc_gauge_train_backward has run. */
+int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float beta, const float* x0, const float* v0,
+                              const int32_t* dir, int64_t rows, float* x_out, float* v_out, float* sumlogdet,
+                              float* p_accept, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+/* dx, dv: [rows][D] = d loss / d (x_N, v_N) on entry, overwritten (d loss / d (x_0, v_0) on exit);
+ * dlogdet: [rows] = d loss / d sumlogdet.  gx, gv, deps (1 float) are overwritten with the gradients. */
+int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
+                               float* dx, float* dv, const float* dlogdet, const l2hmc_dense_grads* gx,
+                               const l2hmc_dense_grads* gv, float* deps, void* ws, size_t ws_bytes,
+                               l2hmc_stream_t stream);
+/* Loss (gauge_model.py:728-797) and its gradient with respect to the proposed states of the 2B stacked
+ * chains (rows [0,B): started at x; rows [B,2B): started at z), through the accept probabilities
+ * (gauge_dynamics.py:592-609).  x0, xN, vN: [2B][2*T*X]; p: [2B]; inv_count = 1 / (number of chains the
+ * mean of :795 runs over, all ranks); terms: [B] or NULL; dxN, dvN: [2B][D]; dlogdet: [2B]. */
+int l2hmc_gauge_loss_backward(int32_t T, int32_t X, float beta, const float* x0, const float* xN,
+                              const float* vN, const float* p, int64_t B, int32_t metric, float loss_scale,
+                              float aux_weight, float std_weight, float charge_weight, float inv_count,
+                              float* terms, float* dxN, float* dvN, float* dlogdet, l2hmc_stream_t stream);
+/* *out (device) = [*out +] sum g[i]^2, elements in [tri_lo, tri_hi) counted three times (the packed
+ * first-layer bias stands for three reference variables); fixed summation order. */
+int l2hmc_grad_sumsq(const float* g, int64_t n, int64_t tri_lo, int64_t tri_hi, float* out, int32_t accumulate,
+                     l2hmc_stream_t stream);
+/* Adam as tf.train.AdamOptimizer applies it: m, v moments; lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is
+ * computed by the caller; w -= lr_t * m / (sqrt(v) + eps).  gnorm_sq (device scalar) != NULL applies
+ * tf.clip_by_global_norm(clip) first.  Elements in [tri_lo, tri_hi) move three times as far (see above). */
+int l2hmc_adam_step(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                    float beta2, float eps, const float* gnorm_sq, float clip, int64_t tri_lo, int64_t tri_hi,
+                    l2hmc_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Generic integrator on 2-D toy targets (MoG / SCG):

@@ -26,6 +26,10 @@ class DenseNet(C.Structure):
                 ("q_tanh", C.c_int32), ("reserved", C.c_int32), ("packed", c_float_p)]
 
 
+class DenseGrads(C.Structure):
+    _fields_ = [(n, c_float_p) for n in ("w1_t", "wt", "b1", "wh_t", "bh", "whd_t", "bhd", "coeff_s", "coeff_q")]
+
+
 class Conv3DFront(C.Structure):
     _fields_ = [("F", C.c_int32), ("reserved", C.c_int32),
                 ("w1_a", c_float_p), ("b1_a", c_float_p), ("w2_a", c_float_p), ("b2_a", c_float_p),
@@ -80,6 +84,15 @@ _PROTOS = {
     "l2hmc_gauge_mcmc_step": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _U64, _U64, _P, _P, _P, _P, _P, _P,
                                         _SZ, _P]),
     "l2hmc_gauge_loss_terms": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
+    "l2hmc_gauge_train_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
+    "l2hmc_gauge_train_forward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ,
+                                            _P]),
+    "l2hmc_gauge_train_backward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _P, _P, _P,
+                                             C.POINTER(DenseGrads), C.POINTER(DenseGrads), _P, _P, _SZ, _P]),
+    "l2hmc_gauge_loss_backward": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _P, _P,
+                                            _P, _P, _P]),
+    "l2hmc_grad_sumsq": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P]),
+    "l2hmc_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _I64, _I64, _P]),
     "l2hmc_mog_energy_grad": (C.c_int, [C.POINTER(MogTarget), _P, _I64, _P, _P, _P]),
     "l2hmc_small_trajectory": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "l2hmc_profile_begin": (C.c_int, [_I32]),

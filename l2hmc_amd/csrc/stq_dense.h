@@ -19,6 +19,8 @@ struct GemmReluArgs {
   int64_t rows;
   int mtiles, ntiles;
   unsigned long long* stamps;          // diagnostic builds only (-DL2HMC_STAMPS), else NULL
+  int kind;                            // 0: relu layer (forward); 3: out = product where gate > 0; 4: plain product
+  const float* gate; int ldg;          // kind 3: forward activations [rows][N]
 };
 
 // heads: (S,T,Q) = h2 . Whd^T + bhd, then materialise or fused v/x update

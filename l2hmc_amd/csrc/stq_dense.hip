@@ -48,6 +48,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // KIND 1: first layer (two k-contiguous sources, optional column mask, time term)
 // KIND 2: hidden layer (single source, plain bias)
+// KIND 3: backward-data through a relu layer: out = (A . Wt^T) where gate > 0, else 0   (no bias)
+// KIND 4: plain product out = A . Wt^T
 template <int BM, int KIND, int BK>
 __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int BN = 128;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * 64 + j * 32 + r;
     const bool cok = col < p.N;
-    const float bj = cok ? p.bias[col] : 0.f;
+    const float bj = (KIND <= 2 && cok) ? p.bias[col] : 0.f;
     const float w0 = (KIND == 1 && cok && p.wt0) ? p.wt0[col] : 0.f;
     const float w1 = (KIND == 1 && cok && p.wt0) ? p.wt1[col] : 0.f;
 #pragma unroll
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
             const float ts = d ? p.ts_b : p.ts_f;
             h += tc * w0 + ts * w1;
           }
-          p.out[row * p.ldo + col] = fmaxf(h, 0.f);
+          if (KIND == 3) h = p.gate[row * p.ldg + col] > 0.f ? h : 0.f;
+          p.out[row * p.ldo + col] = KIND <= 2 ? fmaxf(h, 0.f) : h;
         }
       }
     }
@@ -430,6 +433,22 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   const int64_t t128 = ceil_div(a.rows, 128) * a.ntiles;
   const bool first = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr;
   const int cls = first ? kProfGemmL1 : kProfGemmL2;
+  if (a.kind >= 3) {
+    // backward-data products of the training path (train.hip): same tiles, different epilogue
+    L2HMC_REQUIRE(!first && (a.kind == 4 || a.gate != nullptr), "gemm: bad backward-data descriptor");
+    const bool big = t128 >= 512;
+    a.mtiles = (int)ceil_div(a.rows, big ? 128 : 64);
+    const dim3 grid(a.mtiles * a.ntiles);
+    if (big) {
+      if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<128, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<128, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else {
+      if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+    }
+    L2HMC_CHECK_LAUNCH("gemm_bwd_data");
+    return L2HMC_OK;
+  }
   prof_before(cls, stream);
   // 64-deep k-tiles halve the number of barriers (K ranges must be multiples of 64); their 102 KB of LDS allow one
   // workgroup per CU, so they are used when the grid has at most one workgroup per CU anyway -- larger grids

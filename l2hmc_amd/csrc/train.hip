@@ -1,0 +1,1073 @@
+// Training path of the lattice sampler on gfx950: the loss's gradient with respect to every network
+// weight and the step size -- what tf.gradients(loss, dynamics.variables) builds in
+//   l2hmc/gauge_model.py:799-830 (_calc_loss_and_grads)
+// for the graph of
+//   l2hmc/dynamics/gauge_dynamics.py:195-313, :412-609 (transition kernel, sub-updates)
+//   l2hmc/network/generic_net.py:129-146              (S/T/Q network)
+//   l2hmc/gauge_model.py:728-797                      (loss)
+// and the Adam update of tf.train.AdamOptimizer (gauge_model.py:942-969).
+//
+// Design (reverse mode by hand, no autograd engine):
+//  * forward ("taped") pass: the layered kernels of stq_dense.hip with every intermediate a network
+//    call produces kept in HBM -- first-layer input [a | b*mask], h1, h2, (S,T,Q) and the state the
+//    sub-update consumed.  At the benchmark size that is 31 MB per network call, 1.3 GB per
+//    trajectory of a 288 GB part; nothing is recomputed.
+//  * backward pass: sub-updates in reverse order.  Per network call one element-wise kernel turns the
+//    upstream (dx, dv, dlogdet) into the pre-activation gradients of the three heads, three "NT"
+//    MFMA products (same tiles as the forward, epilogue = relu gate) carry them back to the inputs,
+//    and the force's Hessian-vector product closes the loop through grad_action.
+//  * weight gradients are NOT formed per call: the deltas are taped too, and after the loop one
+//    split-k "TN" MFMA product per weight matrix contracts over all calls x rows at once (81920
+//    rows at the benchmark size), written in the k-contiguous layout the weights are stored in, so
+//    the optimiser is one element-wise pass over a flat buffer and the data-parallel all-reduce is
+//    one bucket per network.
+//  * every reduction runs in a fixed order (no float atomics): results are reproducible.
+#include "stq_dense.h"
+#include <math.h>
+
+namespace l2hmc {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// =====================================================================
+// forward helpers
+// =====================================================================
+
+// in[row] = [a | b * mask(dir)],  st[row] = state   (one wave per row)
+__global__ __launch_bounds__(256) void tape_in_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ cm_f,
+                                                      const float* __restrict__ cm_b,
+                                                      const int* __restrict__ dir,
+                                                      const float* __restrict__ state, int64_t rows, int D,
+                                                      float* __restrict__ in, float* __restrict__ st) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d = dir ? dir[row] : 0;
+  const float* cm = cm_f ? (d ? cm_b : cm_f) : nullptr;
+  for (int c = lane; c < D; c += kWave) {
+    in[row * 2 * D + c] = a[row * D + c];
+    in[row * 2 * D + D + c] = b[row * D + c] * (cm ? cm[c] : 1.f);
+    st[row * D + c] = state[row * D + c];
+  }
+}
+
+// sub-update from materialised S/T/Q (gauge_dynamics.py:486-590), in place, logdet += (one wave per row)
+__global__ __launch_bounds__(256) void train_update_kernel(int mode, const float* __restrict__ stq, int64_t plane,
+                                                           const float* __restrict__ g,
+                                                           const float* __restrict__ keep_f,
+                                                           const float* __restrict__ keep_b,
+                                                           const int* __restrict__ dir, float eps, int64_t rows,
+                                                           int D, float* x, float* v, float* ld) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d = dir ? dir[row] : 0;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += kWave) {
+    const int64_t i = row * D + c;
+    const float S = stq[i], T = stq[plane + i], Q = stq[2 * plane + i];
+    if (mode == 1) {
+      const float s = (d ? -0.5f : 0.5f) * eps * S;
+      const float kick = 0.5f * eps * (expf(eps * Q) * g[i] - T);
+      const float vv = v[i];
+      v[i] = d ? expf(s) * (vv + kick) : vv * expf(s) - kick;
+      acc += s;
+    } else {
+      const float k = (d ? keep_b : keep_f)[c];
+      const float s = (d ? -eps : eps) * S;
+      const float drift = eps * (expf(eps * Q) * v[i] + T);
+      const float xx = x[i];
+      const float upd = d ? expf(s) * (xx - drift) : xx * expf(s) + drift;
+      x[i] = k * xx + (1.f - k) * upd;
+      acc += (1.f - k) * s;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) ld[row] += acc;
+}
+
+__global__ void train_accept_kernel(const float* __restrict__ act0, const float* __restrict__ kin0,
+                                    const float* __restrict__ act1, const float* __restrict__ kin1,
+                                    const float* __restrict__ ld, float beta, int64_t rows,
+                                    float* __restrict__ sumlogdet, float* __restrict__ p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const double h0 = (double)beta * act0[i] + kin0[i], h1 = (double)beta * act1[i] + kin1[i];
+  if (sumlogdet) sumlogdet[i] = ld[i];
+  if (p) p[i] = accept_from_delta((float)(h0 - h1 + (double)ld[i]));
+}
+
+__global__ void invert_mask_train_kernel(const float* __restrict__ m, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.f - m[i];
+}
+
+// =====================================================================
+// backward of one sub-update: upstream (dx, dv, dlogdet) -> head pre-activation gradients,
+// direct force gradient, coefficient / step-size partials.  A thread owns columns and walks its
+// block's rows in order, so the per-block column sums are deterministic.
+// =====================================================================
+constexpr int kUpdRows = 8;
+
+struct UpdBwdArgs {
+  int mode;                         // 1: momentum update, 2: position update
+  int64_t rows; int D; float eps;
+  const float* stq; int64_t plane;  // forward S, T, Q
+  const float* st;                  // state the update consumed: v (mode 1) / x (mode 2)
+  const float* in;                  // [rows][2D]: (x, g) in mode 1, (v, m*x) in mode 2
+  const float* keep_f; const float* keep_b;
+  const int* dir;
+  const float* cs; const float* cq; int q_tanh;
+  const float* dld;                 // [rows]
+  float* dx; float* dv;             // in/out [rows][D]
+  float* dg;                        // mode 1 out [rows][D]
+  float* dout;                      // [rows][3D]
+  float* dcs_part; float* dcq_part; // [nblk][D], +=
+  float* deps_part;                 // [nblk], +=
+};
+
+__global__ __launch_bounds__(256) void update_bwd_kernel(UpdBwdArgs p) {
+  __shared__ float red[4];
+  const int D = p.D;
+  const int64_t r0 = (int64_t)blockIdx.x * kUpdRows;
+  const int64_t r1 = r0 + kUpdRows < p.rows ? r0 + kUpdRows : p.rows;
+  const float eps = p.eps;
+  float deps = 0.f;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float ecs = expf(p.cs[c]), ecq = expf(p.cq[c]);
+    float dcs = 0.f, dcq = 0.f;
+    for (int64_t row = r0; row < r1; ++row) {
+      const int64_t i = row * D + c;
+      const int d = p.dir ? p.dir[row] : 0;
+      const float S = p.stq[i], T = p.stq[p.plane + i], Q = p.stq[2 * p.plane + i];
+      const float dl = p.dld[row];
+      const float eq = expf(eps * Q);
+      float dS, dT, dQ;
+      if (p.mode == 1) {
+        const float v = p.st[i], g = p.in[row * 2 * D + D + c], u = p.dv[i];
+        const float he = 0.5f * eps;
+        if (!d) {
+          const float es = expf(he * S);
+          const float ds = u * v * es + dl;
+          p.dv[i] = u * es;
+          dS = ds * he; dT = u * he; dQ = -u * he * eq * g * eps;
+          p.dg[i] = -u * he * eq;
+          deps += ds * 0.5f * S - u * 0.5f * (eq * g - T) - u * he * g * eq * Q;
+        } else {
+          const float es = expf(-he * S);
+          const float kick = he * (eq * g - T);
+          const float vp = es * (v + kick);
+          const float dw = u * es;
+          const float ds = u * vp + dl;
+          p.dv[i] = dw;
+          dS = -he * ds; dT = -dw * he; dQ = dw * he * eq * g * eps;
+          p.dg[i] = dw * he * eq;
+          deps += -0.5f * S * ds + dw * 0.5f * (eq * g - T) + dw * he * g * eq * Q;
+        }
+      } else {
+        const float k = (d ? p.keep_b : p.keep_f)[c], mi = 1.f - k;
+        const float x = p.st[i], v = p.in[row * 2 * D + c], u = p.dx[i];
+        const float dy = mi * u;
+        if (!d) {
+          const float es = expf(eps * S);
+          const float ds = dy * x * es + dl * mi;
+          p.dx[i] = k * u + dy * es;
+          p.dv[i] += dy * eps * eq;
+          dS = eps * ds; dT = dy * eps; dQ = dy * eps * eq * v * eps;
+          deps += ds * S + dy * (eq * v + T) + dy * eps * v * eq * Q;
+        } else {
+          const float es = expf(-eps * S);
+          const float w = x - eps * (eq * v + T);
+          const float dw = dy * es;
+          const float ds = dy * (es * w) + dl * mi;
+          p.dx[i] = k * u + dw;
+          p.dv[i] -= dw * eps * eq;
+          dS = -eps * ds; dT = -dw * eps; dQ = -dw * eps * eq * v * eps;
+          deps += -S * ds - dw * (eq * v + T) - dw * eps * v * eq * Q;
+        }
+      }
+      // through tanh(.) * exp(coeff) (generic_net.py:139-144)
+      const float th = S / ecs;
+      float daq = dQ * ecq;
+      if (p.q_tanh) {
+        const float tq = Q / ecq;
+        daq *= 1.f - tq * tq;
+      }
+      dcs += dS * S;
+      dcq += dQ * Q;
+      float* o = p.dout + row * 3 * D + c;
+      o[0] = dS * ecs * (1.f - th * th);
+      o[D] = dT;
+      o[2 * D] = daq;
+    }
+    p.dcs_part[(int64_t)blockIdx.x * D + c] += dcs;
+    p.dcq_part[(int64_t)blockIdx.x * D + c] += dcq;
+  }
+  deps = wave_sum(deps);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = deps;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    p.deps_part[blockIdx.x] += t;
+  }
+}
+
+// position-network inputs (v, m*x): dv += din[:, :D], dx += m * din[:, D:]
+__global__ __launch_bounds__(256) void xnet_in_bwd_kernel(const float* __restrict__ din,
+                                                          const float* __restrict__ cm_f,
+                                                          const float* __restrict__ cm_b,
+                                                          const int* __restrict__ dir, int64_t rows, int D,
+                                                          float* dx, float* dv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* cm = (dir && dir[row]) ? cm_b : cm_f;
+  for (int c = lane; c < D; c += kWave) {
+    dv[row * D + c] += din[row * 2 * D + c];
+    dx[row * D + c] += cm[c] * din[row * 2 * D + D + c];
+  }
+}
+
+// momentum-network inputs (x, g = beta * grad_action(x)):
+//   dx += din[:, :D] + beta * Hess(action)(x) . (dg + din[:, D:])
+// The Hessian-vector product has the force's stencil with sin(P) replaced by cos(P) * P[u]
+// (lattice.py:246-262 differentiated once more).  One wave per chain, chain staged in LDS.
+__global__ __launch_bounds__(256) void vnet_in_bwd_kernel(const float* __restrict__ din,
+                                                          const float* __restrict__ dg,
+                                                          const float* __restrict__ in, float beta, int T,
+                                                          int X, int64_t rows, float* dx) {
+  extern __shared__ float lds[];
+  const int D = 2 * T * X, sites = T * X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  float* xs = lds + (size_t)wave * (2 * D + sites);
+  float* us = xs + D;
+  float* cp = us + D;
+  if (row < rows) {
+    for (int c = lane; c < D; c += kWave) {
+      xs[c] = in[row * 2 * D + c];
+      us[c] = dg[row * D + c] + din[row * 2 * D + D + c];
+    }
+  }
+  __syncthreads();
+  if (row < rows) {
+    for (int s = lane; s < sites; s += kWave) {
+      const int i = s / X, j = s - i * X;
+      const int jr = (j + 1 == X) ? 0 : j + 1, id = (i + 1 == T) ? 0 : i + 1;
+      const int e = 2 * s, er = 2 * (i * X + jr), ed = 2 * (id * X + j);
+      const float P = xs[e] - xs[e + 1] - xs[er] + xs[ed + 1];
+      const float Pu = us[e] - us[e + 1] - us[er] + us[ed + 1];
+      cp[s] = cosf(P) * Pu;
+    }
+  }
+  __syncthreads();
+  if (row < rows) {
+    for (int s = lane; s < sites; s += kWave) {
+      const int i = s / X, j = s - i * X;
+      const int jl = (j == 0) ? X - 1 : j - 1, iu = (i == 0) ? T - 1 : i - 1;
+      const float c = cp[s];
+      const float h0 = c - cp[i * X + jl], h1 = -c + cp[iu * X + j];
+      dx[row * D + 2 * s] += din[row * 2 * D + 2 * s] + beta * h0;
+      dx[row * D + 2 * s + 1] += din[row * 2 * D + 2 * s + 1] + beta * h1;
+    }
+  }
+}
+
+// =====================================================================
+// weight gradients: C[m][n] = sum_r P[r][m] * Q[r][n]   ("TN", contraction over rows)
+// 128 x 128 tile per workgroup, 16 rows per stage, fp32 32x32x2 MFMAs.  Tiles are staged exactly as
+// they lie in memory ([r][m]): the MFMA operand of lane (k, m) is then a single ds_read_b32 whose
+// 64 lanes hit 64 different banks (row stride 160 floats = 32 mod 64).  The contraction is split
+// over `splits` workgroups per tile; partials are summed in a fixed order afterwards.
+// =====================================================================
+struct GemmTnArgs {
+  const float* P; int ldp; int M;
+  const float* Q; int ldq; int N;
+  int64_t R;            // contraction length
+  int64_t chunk;        // rows per split (multiple of 16)
+  float* part;          // [splits][M][N]
+  int mt, nt;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
+  constexpr int BM = 128, BN = 128, BKR = 16, LDT = 160;
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BKR * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, r = lane & 31;
+  const int tiles = p.mt * p.nt;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+  const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
+  const int64_t rbeg = (int64_t)split * p.chunk;
+  const int64_t rend = rbeg + p.chunk < p.R ? rbeg + p.chunk : p.R;
+
+  // staging: 16 rows x 32 16-byte chunks per operand = 512 chunks, 2 per thread
+  f32x4 rp[2], rq[2];
+  auto load_stage = [&](int64_t rr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 5, col = (c & 31) * 4;
+      const int64_t gr = rr + row;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (gr < rend) {
+        if (m0 + col < p.M) a = *reinterpret_cast<const f32x4*>(p.P + gr * p.ldp + m0 + col);
+        if (n0 + col < p.N) b = *reinterpret_cast<const f32x4*>(p.Q + gr * p.ldq + n0 + col);
+      }
+      rp[i] = a;
+      rq[i] = b;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* ps = lds + buf * 2 * BKR * LDT;
+    float* qs = ps + BKR * LDT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 5, col = (c & 31) * 4;
+      *reinterpret_cast<f32x4*>(ps + row * LDT + col) = rp[i];
+      *reinterpret_cast<f32x4*>(qs + row * LDT + col) = rq[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (rbeg < rend) {
+    load_stage(rbeg);
+    store_stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t rr = rbeg; rr < rend; rr += BKR) {
+      const bool more = rr + BKR < rend;
+      if (more) load_stage(rr + BKR);
+      const float* ps = lds + cur * 2 * BKR * LDT + wm * 64 + r;
+      const float* qs = lds + cur * 2 * BKR * LDT + BKR * LDT + wn * 64 + r;
+#pragma unroll
+      for (int kk = 0; kk < BKR / 2; ++kk) {
+        const int k = 2 * kk + half;
+        const float a0 = ps[k * LDT], a1 = ps[k * LDT + 32];
+        const float b0 = qs[k * LDT], b1 = qs[k * LDT + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      if (more) store_stage(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = p.part + (size_t)split * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < p.M && col < p.N) out[(size_t)row * p.N + col] = acc[i][j][e];
+      }
+    }
+}
+
+// out[i] = sum_s part[s][i]  (fixed order)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t count,
+                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += part[(size_t)s * count + i];
+  out[i] = t;
+}
+
+// column sums of a taped [calls * rows][n] array (bias gradients), optionally also weighted by the
+// (cos, sin) time input of each (call, row) -- the t_layer kernel's gradient (generic_net.py:131).
+// grid (ceil(n/256), S); part: [S][3][n] (plain, cos-weighted, sin-weighted)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t Rt, int n,
+                                                     int64_t rows, int nsteps, const int* __restrict__ dir,
+                                                     int timed, int64_t chunk, float* __restrict__ part) {
+  extern __shared__ float tab[];   // [nsteps][2] (cos, sin)
+  if (timed) {
+    for (int i = threadIdx.x; i < nsteps; i += blockDim.x) {
+      const float ang = (float)(2.0 * M_PI) * (float)i / (float)nsteps;
+      tab[2 * i] = cosf(ang);
+      tab[2 * i + 1] = sinf(ang);
+    }
+    __syncthreads();
+  }
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  const int64_t rb = (int64_t)blockIdx.y * chunk;
+  const int64_t re = rb + chunk < Rt ? rb + chunk : Rt;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int64_t rr = rb; rr < re; ++rr) {
+    const float v = src[rr * n + col];
+    s0 += v;
+    if (timed) {
+      const int64_t call = rr / rows, row = rr - call * rows;
+      const int step = (int)(call >> 1);
+      const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
+      s1 += tab[2 * i] * v;
+      s2 += tab[2 * i + 1] * v;
+    }
+  }
+  float* o = part + (size_t)blockIdx.y * 3 * n;
+  o[col] = s0;
+  o[n + col] = s1;
+  o[2 * n + col] = s2;
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int Cn,
+                                                        float* __restrict__ out) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8)
+    if (r0 + k < R && c0 + tx < Cn) t[k][tx] = in[(size_t)(r0 + k) * Cn + c0 + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < Cn && r0 + tx < R) out[(size_t)(c0 + k) * R + r0 + tx] = t[tx][k];
+}
+
+// =====================================================================
+// loss backward (gauge_model.py:728-797) + the accept probability's dependence on the final state
+// (gauge_dynamics.py:284-313, :592-609):  d loss / d (x_N, v_N, sumlogdet) for the 2B stacked chains
+// (rows [0,B): chains started at x, rows [B,2B): chains started at the auxiliary z).
+// One wave per (x, z) pair.
+// =====================================================================
+struct LossBwdArgs {
+  int T, X; int64_t B; float beta;
+  const float* x0;   // [2B][D] initial states (x rows, then z rows)
+  const float* xN; const float* vN;   // [2B][D] proposed states
+  const float* p;    // [2B]
+  int metric; float loss_scale, aux_weight, std_weight, charge_weight, inv_count;
+  float* terms;      // [B] per-chain loss (forward value) or NULL
+  float* dxN; float* dvN;   // [2B][D]
+  float* dld;        // [2B]
+};
+
+__device__ __forceinline__ float metric_val(int m, float a, float b) {
+  switch (m) {
+    case 0: return fabsf(a - b);
+    case 1: return (a - b) * (a - b);
+    case 2: return fabsf(cosf(a) - cosf(b));
+    case 3: { const float c = cosf(a) - cosf(b); return c * c; }
+    default: return 1.f - cosf(a - b);
+  }
+}
+// d metric(a, b) / d b
+__device__ __forceinline__ float metric_db(int m, float a, float b) {
+  switch (m) {
+    case 0: return a > b ? -1.f : (a < b ? 1.f : 0.f);
+    case 1: return -2.f * (a - b);
+    case 2: { const float c = cosf(a) - cosf(b); return (c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f)) * sinf(b); }
+    case 3: return 2.f * (cosf(a) - cosf(b)) * sinf(b);
+    default: return -sinf(a - b);
+  }
+}
+// 4-term Fourier series of the plaquette projection and its derivative (lattice.py:108-128)
+__device__ __forceinline__ void proj_series(float P, float& f, float& df) {
+  f = 0.f; df = 0.f;
+  float sgn = -1.f;
+#pragma unroll
+  for (int n = 1; n <= 4; ++n) {
+    f += (-2.f / n) * sgn * sinf(n * P);
+    df += -2.f * sgn * cosf(n * P);
+    sgn = -sgn;
+  }
+}
+
+__device__ __forceinline__ float plaq_at(const float* xs, int s, int T, int X) {
+  const int i = s / X, j = s - i * X;
+  const int jr = (j + 1 == X) ? 0 : j + 1, id = (i + 1 == T) ? 0 : i + 1;
+  return xs[2 * s] - xs[2 * s + 1] - xs[2 * (i * X + jr)] + xs[2 * (id * X + j) + 1];
+}
+
+__global__ __launch_bounds__(64) void loss_bwd_kernel(LossBwdArgs p) {
+  extern __shared__ float lds[];
+  const int T = p.T, X = p.X, sites = T * X, D = 2 * sites;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  float* xs = lds;            // [D] staged chain
+  float* cp = xs + D;         // [sites] d q / d plaquette of x'
+  float* sp = cp + sites;     // [sites] sin(plaquette)
+  const float kTwoPiInv = 0.15915494309189535f;
+  const float* x = p.x0 + b * D;
+  const float* z = p.x0 + (p.B + b) * D;
+  const float* xp = p.xN + b * D;
+
+  auto charge_of = [&](const float* src) {
+    __syncthreads();
+    for (int c = lane; c < D; c += 64) xs[c] = src[c];
+    __syncthreads();
+    float q = 0.f;
+    for (int s = lane; s < sites; s += 64) {
+      float f, df;
+      proj_series(plaq_at(xs, s, T, X), f, df);
+      q += f;
+    }
+    return wave_sum(q) * kTwoPiInv;
+  };
+  const float qx = charge_of(x);
+  const float qz = charge_of(z);
+  // proposed x-chain state: charge, d charge / d plaquette, sin(plaquette) for the force
+  __syncthreads();
+  for (int c = lane; c < D; c += 64) xs[c] = xp[c];
+  __syncthreads();
+  float qp = 0.f;
+  for (int s = lane; s < sites; s += 64) {
+    const float P = plaq_at(xs, s, T, X);
+    float f, df;
+    proj_series(P, f, df);
+    qp += f;
+    cp[s] = df * kTwoPiInv;
+    sp[s] = sinf(P);
+  }
+  qp = wave_sum(qp) * kTwoPiInv;
+  float mx = 0.f, mz = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    mx += metric_val(p.metric, x[c], xs[c]);
+    mz += metric_val(p.metric, z[c], xs[c]);
+  }
+  mx = wave_sum(mx);
+  mz = wave_sum(mz);
+  const float px = p.p[b], pz = p.p[p.B + b];
+  const float e = 1e-3f;                       // gauge_model.py:745
+  const float ls = p.loss_scale, aw = p.aux_weight, sw = p.std_weight, cw = p.charge_weight;
+  const float xstd = mx * px + e, zstd = aw * (mz * pz + e);
+  const float dqx = qx - qp, dqz = qz - qp;
+  const float xq = px * fabsf(dqx) + e, zq = aw * (pz * fabsf(dqz) + e);
+  if (p.terms && lane == 0)
+    p.terms[b] = sw * (ls * (1.f / xstd + 1.f / zstd) - (xstd + zstd) / ls) + cw * (xq + zq);
+  const float w = p.inv_count;
+  const float ax = w * sw * (-ls / (xstd * xstd) - 1.f / ls);
+  const float az = w * sw * (-ls / (zstd * zstd) - 1.f / ls) * aw;
+  const float dpx = ax * mx + w * cw * fabsf(dqx);
+  const float dpz = az * mz + w * cw * aw * fabsf(dqz);
+  // d / d q(x'):  xq, zq depend on |q - q'|
+  const float sgx = dqx > 0.f ? 1.f : (dqx < 0.f ? -1.f : 0.f), sgz = dqz > 0.f ? 1.f : (dqz < 0.f ? -1.f : 0.f);
+  const float dqp = -w * cw * (px * sgx + aw * pz * sgz);
+  // accept probability: p = exp(min(H0 - H1 + ld, 0)) -> d p / d(.) = p where p < 1
+  const float ddx = (px < 1.f) ? dpx * px : 0.f;
+  const float ddz = (pz < 1.f) ? dpz * pz : 0.f;
+  if (lane == 0) {
+    p.dld[b] = ddx;
+    p.dld[p.B + b] = ddz;
+  }
+  __syncthreads();
+  for (int s = lane; s < sites; s += 64) {
+    const int i = s / X, j = s - i * X;
+    const int jl = (j == 0) ? X - 1 : j - 1, iu = (i == 0) ? T - 1 : i - 1;
+    const int sl = i * X + jl, su = iu * X + j;
+#pragma unroll
+    for (int mu = 0; mu < 2; ++mu) {
+      const int c = 2 * s + mu;
+      const float dq = mu == 0 ? cp[s] - cp[sl] : -cp[s] + cp[su];
+      const float frc = p.beta * (mu == 0 ? sp[s] - sp[sl] : -sp[s] + sp[su]);
+      const float a = xs[c];
+      p.dxN[b * D + c] = ax * px * metric_db(p.metric, x[c], a) + az * pz * metric_db(p.metric, z[c], a) +
+                         dqp * dq - ddx * frc;
+      p.dvN[b * D + c] = -ddx * p.vN[b * D + c];
+    }
+  }
+  // auxiliary chain: only its accept probability enters the loss
+  __syncthreads();
+  const float* zp = p.xN + (p.B + b) * D;
+  for (int c = lane; c < D; c += 64) xs[c] = zp[c];
+  __syncthreads();
+  for (int s = lane; s < sites; s += 64) sp[s] = sinf(plaq_at(xs, s, T, X));
+  __syncthreads();
+  for (int s = lane; s < sites; s += 64) {
+    const int i = s / X, j = s - i * X;
+    const int jl = (j == 0) ? X - 1 : j - 1, iu = (i == 0) ? T - 1 : i - 1;
+    const int sl = i * X + jl, su = iu * X + j;
+    const int64_t o = (p.B + b) * D + 2 * s;
+    p.dxN[o] = -ddz * p.beta * (sp[s] - sp[sl]);
+    p.dxN[o + 1] = -ddz * p.beta * (-sp[s] + sp[su]);
+    p.dvN[o] = -ddz * p.vN[o];
+    p.dvN[o + 1] = -ddz * p.vN[o + 1];
+  }
+}
+
+// =====================================================================
+// optimiser: tf.train.AdamOptimizer.apply_gradients with optional clip_by_global_norm
+// (gauge_model.py:826-827, :942-969)
+// =====================================================================
+// sum of squares in a fixed order: one workgroup, 1024 threads.  Elements in [tri_lo, tri_hi) count
+// three times (the packed first-layer bias stands for the reference's three bias variables).
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, int64_t tri_lo,
+                                                     int64_t tri_hi, float* out, int accumulate) {
+  __shared__ float red[16];
+  float t = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = g[i];
+    t += ((i >= tri_lo && i < tri_hi) ? 3.f : 1.f) * v * v;
+  }
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    *out = accumulate ? *out + s : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr_t, float b1, float b2, float eps,
+                                                   const float* __restrict__ gnorm_sq, float clip,
+                                                   int64_t tri_lo, int64_t tri_hi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float scale = 1.f;
+  if (gnorm_sq) {
+    // tf.clip_by_global_norm: g * clip / max(norm, clip)
+    const float norm = sqrtf(*gnorm_sq);
+    scale = clip / fmaxf(norm, clip);
+  }
+  const float gi = g[i] * scale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float step = lr_t * mi / (sqrtf(vi) + eps);
+  w[i] -= ((i >= tri_lo && i < tri_hi) ? 3.f : 1.f) * step;
+}
+
+// =====================================================================
+// host orchestration
+// =====================================================================
+struct NetTape {
+  float *in, *h1, *h2, *stq, *st, *d1, *d2, *dout;   // [calls][rows][.]
+  float *dcs_part, *dcq_part;                         // [nblk][D]
+};
+struct TrainWs {
+  NetTape x, v;
+  float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *wT, *part, *eps_part, *xw, *vw;
+  size_t bytes;
+};
+
+static inline int64_t imax64(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
+static int64_t upd_blocks(int64_t rows) { return ceil_div(rows, kUpdRows); }
+static int tn_splits(int mt, int nt, int64_t R) {
+  int s = (int)imax64(1, 512 / ((int64_t)mt * nt));
+  const int64_t maxs = imax64(1, ceil_div(R, 256));   // at least 256 rows per split
+  return (int)hmin(s, maxs);
+}
+
+static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws) {
+  TrainWs w{};
+  const int D = 2 * p->T * p->X;
+  const int C = 2 * p->num_steps;
+  char* base = static_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t nfloats) {
+    float* q = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align_up(nfloats * sizeof(float), 256);
+    return q;
+  };
+  const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
+  NetTape* tapes[2] = {&w.x, &w.v};
+  size_t wt_max = 0, part_max = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int H = nets[k]->H;
+    NetTape& t = *tapes[k];
+    const size_t cr = (size_t)C * rows;
+    t.in = take(cr * 2 * D);
+    t.h1 = take(cr * H);
+    t.h2 = take(cr * H);
+    t.stq = take(cr * 3 * D);
+    t.st = take(cr * D);
+    t.d1 = take(cr * H);
+    t.d2 = take(cr * H);
+    t.dout = take(cr * 3 * D);
+    t.dcs_part = take((size_t)upd_blocks(rows) * D);
+    t.dcq_part = take((size_t)upd_blocks(rows) * D);
+    wt_max = smax(wt_max, smax((size_t)2 * D * H, smax((size_t)H * H, (size_t)3 * D * H)));
+    // split-k partials of the three weight-gradient products and the column sums
+    const int64_t R = (int64_t)cr;
+    auto need = [&](int M, int N) {
+      const int mt = (int)ceil_div(M, 128), nt = (int)ceil_div(N, 128);
+      return (size_t)tn_splits(mt, nt, R) * M * N;
+    };
+    part_max = smax(part_max, smax(need(H, 2 * D), smax(need(H, H), need(3 * D, H))));
+    part_max = smax(part_max, (size_t)65 * 3 * hmax(H, 3 * D));
+  }
+  w.mask_inv = take((size_t)p->num_steps * D);
+  w.ld = take(rows);
+  w.act0 = take(rows); w.kin0 = take(rows); w.act1 = take(rows); w.kin1 = take(rows);
+  w.g = take((size_t)rows * D);
+  w.dg = take((size_t)rows * D);
+  w.din = take((size_t)rows * 2 * D);
+  w.wT = take(wt_max);
+  w.part = take(part_max);
+  w.eps_part = take(upd_blocks(rows));
+  w.xw = take((size_t)rows * D);
+  w.vw = take((size_t)rows * D);
+  w.bytes = off;
+  return w;
+}
+
+static int check_train_plan(const l2hmc_gauge_plan* p) {
+  L2HMC_REQUIRE(p != nullptr, "train: NULL plan");
+  L2HMC_REQUIRE(p->T > 0 && p->X > 0 && p->num_steps > 0 && p->masks != nullptr, "train: bad plan");
+  L2HMC_REQUIRE(!p->hmc, "train: hmc plans have no trainable networks");
+  L2HMC_REQUIRE(!(p->flags & L2HMC_PLAN_CONV3D), "train: ConvNet3D plans are not supported yet (generic nets only)");
+  const int D = 2 * p->T * p->X;
+  const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
+  for (int k = 0; k < 2; ++k) {
+    const l2hmc_dense_net* n = nets[k];
+    L2HMC_REQUIRE(dense_net_supported(n) && n->D == D && n->Ka == D && n->Kb == D,
+                  "train: network widths (D=%d Ka=%d Kb=%d H=%d) must be multiples of 32 with Ka = Kb = D = %d",
+                  n->D, n->Ka, n->Kb, n->H, D);
+    L2HMC_REQUIRE(n->w1_t && n->wt && n->b1 && n->wh_t && n->bh && n->whd_t && n->bhd && n->coeff_s && n->coeff_q,
+                  "train: NULL weight pointer");
+  }
+  return L2HMC_OK;
+}
+
+static void step_times(int N, int step, float tcs[4]) {
+  const float two_pi = (float)(2.0 * M_PI);
+  const float af = two_pi * (float)step / (float)N, ab = two_pi * (float)(N - 1 - step) / (float)N;
+  tcs[0] = cosf(af); tcs[1] = sinf(af); tcs[2] = cosf(ab); tcs[3] = sinf(ab);
+}
+
+// forward of one network call with everything taped, then the sub-update
+static int taped_call(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, const NetTape& t, int call, int mode,
+                      const float* a, const float* b, const float* cm_f, const float* cm_b, const float* state,
+                      const float* keep_f, const float* keep_b, const int* dir, const float tcs[4], int64_t rows,
+                      float* x, float* v, const TrainWs& w, hipStream_t s) {
+  const int D = net->D, H = net->H;
+  const size_t cr = (size_t)call * rows;
+  float* in = t.in + cr * 2 * D;
+  float* h1 = t.h1 + cr * H;
+  float* h2 = t.h2 + cr * H;
+  float* stq = t.stq + cr * 3 * D;
+  const unsigned rgrid = (unsigned)ceil_div(rows, 4);
+  hipLaunchKernelGGL(tape_in_kernel, dim3(rgrid), dim3(256), 0, s, a, b, cm_f, cm_b, dir, state, rows, D, in,
+                     t.st + cr * D);
+  L2HMC_CHECK_LAUNCH("tape_in");
+  GemmReluArgs l1{};
+  l1.A1 = in; l1.lda1 = 2 * D; l1.K1 = 2 * D;
+  l1.dir = dir;
+  l1.Wt = net->w1_t; l1.K = 2 * D; l1.N = H;
+  l1.bias = net->b1; l1.wt0 = net->wt; l1.wt1 = net->wt + H;
+  l1.tc_f = tcs[0]; l1.ts_f = tcs[1]; l1.tc_b = tcs[2]; l1.ts_b = tcs[3];
+  l1.out = h1; l1.ldo = H; l1.rows = rows;
+  if (int e = launch_gemm_relu(l1, s)) return e;
+  GemmReluArgs l2{};
+  l2.A1 = h1; l2.lda1 = H; l2.K1 = H;
+  l2.Wt = net->wh_t; l2.K = H; l2.N = H;
+  l2.bias = net->bh; l2.out = h2; l2.ldo = H; l2.rows = rows;
+  if (int e = launch_gemm_relu(l2, s)) return e;
+  HeadsArgs h{};
+  h.A = h2; h.lda = H; h.K = H;
+  h.Wt = net->whd_t; h.bhd = net->bhd; h.cs = net->coeff_s; h.cq = net->coeff_q;
+  h.q_tanh = net->q_tanh; h.D = D; h.rows = rows; h.mode = kHeadsMaterialise;
+  h.S = stq; h.T = stq + (size_t)rows * D; h.Q = stq + 2 * (size_t)rows * D;
+  if (int e = launch_heads(h, s)) return e;
+  hipLaunchKernelGGL(train_update_kernel, dim3(rgrid), dim3(256), 0, s, mode, stq, (int64_t)rows * D, w.g, keep_f,
+                     keep_b, dir, p->eps, rows, D, x, v, w.ld);
+  L2HMC_CHECK_LAUNCH("train_update");
+  return L2HMC_OK;
+}
+
+// backward of one network call: heads' pre-activation gradients (in t.dout) -> t.d2, t.d1, w.din
+static int call_backward_data(const l2hmc_dense_net* net, const NetTape& t, int call, int64_t rows, const TrainWs& w,
+                              hipStream_t s) {
+  const int D = net->D, H = net->H;
+  const size_t cr = (size_t)call * rows;
+  const dim3 tb(256);
+  // d2 = (dout . Whd) gated by h2 > 0:   B operand [H][3D] = transpose of whd_t [3D][H]
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(3 * D, 32)), tb, 0, s,
+                     net->whd_t, 3 * D, H, w.wT);
+  L2HMC_CHECK_LAUNCH("transpose");
+  GemmReluArgs g2{};
+  g2.kind = 3;
+  g2.A1 = t.dout + cr * 3 * D; g2.lda1 = 3 * D; g2.K1 = 3 * D; g2.K = 3 * D;
+  g2.Wt = w.wT; g2.N = H;
+  g2.gate = t.h2 + cr * H; g2.ldg = H;
+  g2.out = t.d2 + cr * H; g2.ldo = H; g2.rows = rows;
+  if (int e = launch_gemm_relu(g2, s)) return e;
+  // d1 = (d2 . Wh) gated by h1 > 0:      B operand [H_in][H_out] = transpose of wh_t [out][in]
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
+                     net->wh_t, H, H, w.wT);
+  L2HMC_CHECK_LAUNCH("transpose");
+  GemmReluArgs g1{};
+  g1.kind = 3;
+  g1.A1 = t.d2 + cr * H; g1.lda1 = H; g1.K1 = H; g1.K = H;
+  g1.Wt = w.wT; g1.N = H;
+  g1.gate = t.h1 + cr * H; g1.ldg = H;
+  g1.out = t.d1 + cr * H; g1.ldo = H; g1.rows = rows;
+  if (int e = launch_gemm_relu(g1, s)) return e;
+  // din = d1 . W1:                        B operand [2D][H] = transpose of w1_t [H][2D]
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(2 * D, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
+                     net->w1_t, H, 2 * D, w.wT);
+  L2HMC_CHECK_LAUNCH("transpose");
+  GemmReluArgs g0{};
+  g0.kind = 4;
+  g0.A1 = t.d1 + cr * H; g0.lda1 = H; g0.K1 = H; g0.K = H;
+  g0.Wt = w.wT; g0.N = 2 * D;
+  g0.out = w.din; g0.ldo = 2 * D; g0.rows = rows;
+  return launch_gemm_relu(g0, s);
+}
+
+static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, float* out, const TrainWs& w,
+                   hipStream_t s) {
+  GemmTnArgs a{};
+  a.P = P; a.ldp = M; a.M = M; a.Q = Q; a.ldq = N; a.N = N; a.R = R;
+  a.mt = (int)ceil_div(M, 128); a.nt = (int)ceil_div(N, 128);
+  const int splits = tn_splits(a.mt, a.nt, R);
+  a.chunk = (int64_t)align_up((size_t)ceil_div(R, splits), 16);
+  a.part = w.part;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.mt * a.nt * splits), dim3(256), 0, s, a);
+  L2HMC_CHECK_LAUNCH("gemm_tn");
+  const int64_t count = (int64_t)M * N;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, w.part, splits,
+                     count, out);
+  L2HMC_CHECK_LAUNCH("reduce_partials");
+  return L2HMC_OK;
+}
+
+static int colsum(const float* src, int64_t Rt, int n, int64_t rows, int nsteps, const int* dir, int timed,
+                  float* out_plain, float* out_cos, float* out_sin, const TrainWs& w, hipStream_t s) {
+  const int S = (int)hmin(64, imax64(1, Rt / 64));
+  const int64_t chunk = ceil_div(Rt, S);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), sizeof(float) * 2 * nsteps, s,
+                     src, Rt, n, rows, nsteps, dir, timed, chunk, w.part);
+  L2HMC_CHECK_LAUNCH("colsum");
+  // partials are [S][3][n]: reduce each plane with stride 3n
+  // (reduce_partials_kernel sums part[s * count + i]; use count = 3n and a scratch of 3n, then split)
+  float* tmp = w.part + (size_t)S * 3 * n;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(3 * n, 256)), dim3(256), 0, s, w.part, S,
+                     (int64_t)3 * n, tmp);
+  L2HMC_CHECK_LAUNCH("reduce_partials");
+  if (hipMemcpyAsync(out_plain, tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      (timed && (hipMemcpyAsync(out_cos, tmp + n, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                 hipMemcpyAsync(out_sin, tmp + 2 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess))) {
+    set_error("hipMemcpyAsync failed in colsum");
+    return L2HMC_ERR_HIP;
+  }
+  return L2HMC_OK;
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" size_t l2hmc_gauge_train_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows) {
+  if (!plan || rows <= 0 || plan->hmc) return 0;
+  return carve_train_ws(plan, rows, nullptr).bytes;
+}
+
+extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float beta, const float* x0, const float* v0,
+                                         const int32_t* dir, int64_t rows, float* x_out, float* v_out,
+                                         float* sumlogdet, float* p_accept, void* ws, size_t ws_bytes,
+                                         l2hmc_stream_t stream) {
+  if (int e = check_train_plan(plan)) return e;
+  L2HMC_REQUIRE(rows >= 0, "train_forward: rows < 0");
+  if (rows == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x0 && v0 && x_out && v_out && ws, "train_forward: NULL pointer");
+  const TrainWs w = carve_train_ws(plan, rows, ws);
+  if (ws_bytes < w.bytes) {
+    set_error("train_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = 2 * plan->T * plan->X, N = plan->num_steps;
+  const size_t nb = sizeof(float) * (size_t)rows * D;
+  if ((x_out != x0 && hipMemcpyAsync(x_out, x0, nb, hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+      (v_out != v0 && hipMemcpyAsync(v_out, v0, nb, hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+      hipMemsetAsync(w.ld, 0, sizeof(float) * rows, s) != hipSuccess) {
+    set_error("train_forward: copy failed");
+    return L2HMC_ERR_HIP;
+  }
+  hipLaunchKernelGGL(invert_mask_train_kernel, dim3((unsigned)ceil_div(N * D, 256)), dim3(256), 0, s, plan->masks,
+                     w.mask_inv, N * D);
+  L2HMC_CHECK_LAUNCH("invert_mask");
+  float* x = x_out;
+  float* v = v_out;
+  if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, w.act0, nullptr, nullptr, nullptr, s)) return e;
+  if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin0, stream)) return e;
+  for (int step = 0; step < N; ++step) {
+    float tcs[4];
+    step_times(N, step, tcs);
+    const int sf = step, sb = N - 1 - step;
+    const float* m_f = plan->masks + (size_t)sf * D;
+    const float* m_b = plan->masks + (size_t)sb * D;
+    const float* mi_f = w.mask_inv + (size_t)sf * D;
+    const float* mi_b = w.mask_inv + (size_t)sb * D;
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+        for (int sub = 0; sub < 2; ++sub) {
+          // forward rows (gauge_dynamics.py:428-438): (m, m_inv) then (m_inv, m); backward rows (:466-476) swapped
+          const float* kf = sub == 0 ? m_f : mi_f;
+          const float* kb = sub == 0 ? mi_b : m_b;
+          if (int e = taped_call(plan, &plan->xnet, w.x, 2 * step + sub, 2, v, x, kf, kb, x, kf, kb, dir, tcs, rows,
+                                 x, v, w, s))
+            return e;
+        }
+      }
+      if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, nullptr, w.g, nullptr, nullptr, s)) return e;
+      if (int e = taped_call(plan, &plan->vnet, w.v, 2 * step + half, 1, x, w.g, nullptr, nullptr, v, nullptr,
+                             nullptr, dir, tcs, rows, x, v, w, s))
+        return e;
+    }
+  }
+  if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, w.act1, nullptr, nullptr, nullptr, s)) return e;
+  if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin1, stream)) return e;
+  hipLaunchKernelGGL(train_accept_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, w.act0, w.kin0,
+                     w.act1, w.kin1, w.ld, beta, rows, sumlogdet, p_accept);
+  L2HMC_CHECK_LAUNCH("train_accept");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
+                                          float* dx, float* dv, const float* dlogdet,
+                                          const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv, float* deps,
+                                          void* ws, size_t ws_bytes, l2hmc_stream_t stream) {
+  if (int e = check_train_plan(plan)) return e;
+  L2HMC_REQUIRE(rows > 0 && dx && dv && dlogdet && gx && gv && deps && ws, "train_backward: bad arguments");
+  const TrainWs w = carve_train_ws(plan, rows, ws);
+  if (ws_bytes < w.bytes) {
+    set_error("train_backward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = 2 * plan->T * plan->X, N = plan->num_steps, C = 2 * N;
+  const int64_t nblk = upd_blocks(rows);
+  if (hipMemsetAsync(w.x.dcs_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
+      hipMemsetAsync(w.x.dcq_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
+      hipMemsetAsync(w.v.dcs_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
+      hipMemsetAsync(w.v.dcq_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
+      hipMemsetAsync(w.eps_part, 0, sizeof(float) * nblk, s) != hipSuccess) {
+    set_error("train_backward: memset failed");
+    return L2HMC_ERR_HIP;
+  }
+  const unsigned rgrid = (unsigned)ceil_div(rows, 4);
+  const size_t vlds = sizeof(float) * 4 * (size_t)(2 * D + D / 2);
+  L2HMC_REQUIRE(vlds <= 160 * 1024, "train_backward: lattice too large for the force-Hessian kernel's LDS");
+  if (vlds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vnet_in_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
+  const int ublock = (int)hmin(256, (int64_t)align_up((size_t)D, 64));
+  auto upd = [&](const l2hmc_dense_net* net, const NetTape& t, int call, int mode, const float* kf,
+                 const float* kb) -> int {
+    const size_t cr = (size_t)call * rows;
+    UpdBwdArgs a{};
+    a.mode = mode; a.rows = rows; a.D = D; a.eps = plan->eps;
+    a.stq = t.stq + cr * 3 * D; a.plane = (int64_t)rows * D;
+    a.st = t.st + cr * D; a.in = t.in + cr * 2 * D;
+    a.keep_f = kf; a.keep_b = kb; a.dir = dir;
+    a.cs = net->coeff_s; a.cq = net->coeff_q; a.q_tanh = net->q_tanh;
+    a.dld = dlogdet; a.dx = dx; a.dv = dv; a.dg = w.dg;
+    a.dout = t.dout + cr * 3 * D;
+    a.dcs_part = t.dcs_part; a.dcq_part = t.dcq_part; a.deps_part = w.eps_part;
+    hipLaunchKernelGGL(update_bwd_kernel, dim3((unsigned)nblk), dim3(ublock), 0, s, a);
+    L2HMC_CHECK_LAUNCH("update_bwd");
+    return call_backward_data(net, t, call, rows, w, s);
+  };
+  for (int step = N - 1; step >= 0; --step) {
+    const int sf = step, sb = N - 1 - step;
+    const float* m_f = plan->masks + (size_t)sf * D;
+    const float* m_b = plan->masks + (size_t)sb * D;
+    const float* mi_f = w.mask_inv + (size_t)sf * D;
+    const float* mi_b = w.mask_inv + (size_t)sb * D;
+    for (int half = 1; half >= 0; --half) {
+      const int vc = 2 * step + half;
+      if (int e = upd(&plan->vnet, w.v, vc, 1, nullptr, nullptr)) return e;
+      hipLaunchKernelGGL(vnet_in_bwd_kernel, dim3(rgrid), dim3(256), vlds, s, w.din,
+                         w.dg, w.v.in + (size_t)vc * rows * 2 * D, beta, plan->T, plan->X, rows, dx);
+      L2HMC_CHECK_LAUNCH("vnet_in_bwd");
+      if (half == 1) {
+        for (int sub = 1; sub >= 0; --sub) {
+          const float* kf = sub == 0 ? m_f : mi_f;
+          const float* kb = sub == 0 ? mi_b : m_b;
+          if (int e = upd(&plan->xnet, w.x, 2 * step + sub, 2, kf, kb)) return e;
+          hipLaunchKernelGGL(xnet_in_bwd_kernel, dim3(rgrid), dim3(256), 0, s, w.din, kf, kb, dir, rows, D, dx, dv);
+          L2HMC_CHECK_LAUNCH("xnet_in_bwd");
+        }
+      }
+    }
+  }
+  // ---- weight gradients from the tape: one contraction over all calls x rows per matrix
+  const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
+  const NetTape* tapes[2] = {&w.x, &w.v};
+  const l2hmc_dense_grads* gr[2] = {gx, gv};
+  const int64_t Rt = (int64_t)C * rows;
+  for (int k = 0; k < 2; ++k) {
+    const int H = nets[k]->H;
+    const NetTape& t = *tapes[k];
+    const l2hmc_dense_grads* g = gr[k];
+    L2HMC_REQUIRE(g->w1_t && g->wt && g->b1 && g->wh_t && g->bh && g->whd_t && g->bhd && g->coeff_s && g->coeff_q,
+                  "train_backward: NULL gradient pointer");
+    if (int e = gemm_tn(t.d1, H, t.in, 2 * D, Rt, g->w1_t, w, s)) return e;
+    if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
+    if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
+    if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
+    if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
+    if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, t.dcs_part,
+                       (int)nblk, (int64_t)D, g->coeff_s);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, t.dcq_part,
+                       (int)nblk, (int64_t)D, g->coeff_q);
+    L2HMC_CHECK_LAUNCH("reduce_partials");
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, w.eps_part, (int)nblk, (int64_t)1, deps);
+  L2HMC_CHECK_LAUNCH("reduce_partials");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_gauge_loss_backward(int32_t T, int32_t X, float beta, const float* x0, const float* xN,
+                                         const float* vN, const float* p, int64_t B, int32_t metric,
+                                         float loss_scale, float aux_weight, float std_weight, float charge_weight,
+                                         float inv_count, float* terms, float* dxN, float* dvN, float* dlogdet,
+                                         l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(T > 0 && X > 0 && B >= 0 && metric >= 0 && metric <= 4, "loss_backward: bad arguments");
+  if (B == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x0 && xN && vN && p && dxN && dvN && dlogdet, "loss_backward: NULL pointer");
+  LossBwdArgs a{};
+  a.T = T; a.X = X; a.B = B; a.beta = beta; a.x0 = x0; a.xN = xN; a.vN = vN; a.p = p; a.metric = metric;
+  a.loss_scale = loss_scale; a.aux_weight = aux_weight; a.std_weight = std_weight; a.charge_weight = charge_weight;
+  a.inv_count = inv_count; a.terms = terms; a.dxN = dxN; a.dvN = dvN; a.dld = dlogdet;
+  const size_t lds = sizeof(float) * (size_t)(2 * T * X + 2 * T * X);
+  L2HMC_REQUIRE(lds <= 64 * 1024, "loss_backward: lattice too large for one workgroup's LDS");
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, a);
+  L2HMC_CHECK_LAUNCH("loss_bwd");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_grad_sumsq(const float* g, int64_t n, int64_t tri_lo, int64_t tri_hi, float* out,
+                                int32_t accumulate, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(n >= 0 && out, "grad_sumsq: bad arguments");
+  L2HMC_REQUIRE(n == 0 || g, "grad_sumsq: NULL gradient");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, tri_lo, tri_hi, out, accumulate);
+  L2HMC_CHECK_LAUNCH("sumsq");
+  return L2HMC_OK;
+}
+
+extern "C" int l2hmc_adam_step(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                               float beta2, float eps, const float* gnorm_sq, float clip, int64_t tri_lo,
+                               int64_t tri_hi, l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(n >= 0, "adam_step: n < 0");
+  if (n == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(w && g && m && v, "adam_step: NULL pointer");
+  L2HMC_REQUIRE(gnorm_sq == nullptr || clip > 0.f, "adam_step: clip value must be positive");
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
+                     lr_t, beta1, beta2, eps, gnorm_sq, clip, tri_lo, tri_hi);
+  L2HMC_CHECK_LAUNCH("adam");
+  return L2HMC_OK;
+}

@@ -1,0 +1,188 @@
+"""Training step of the lattice sampler on the device:
+  l2hmc/gauge_model.py:728-830  _calc_loss / _calc_loss_and_grads (loss + tf.gradients + clip_by_global_norm)
+  l2hmc/gauge_model.py:925-970  exponential_decay schedule, AdamOptimizer (x hvd.size()), apply_gradients
+  l2hmc/gauge_model.py:1160-1200 one `train_op` evaluation per step.
+
+Everything between "samples in" and "weights updated" is library calls on device buffers
+(include/l2hmc_hip.h, training section); the only host work per step is reading back the new step size,
+which the plan passes by value.  Gradients of all ranks are combined by ONE all-reduce(SUM) of a flat buffer
+[xnet | vnet | eps] -- the loss already divides by the global chain count, so the sum IS the gradient of the
+global mean.  (The reference calls tf.gradients + apply_gradients, which bypasses
+hvd.DistributedOptimizer.compute_gradients: its ranks never exchange gradients.  `allreduce_grads=False`
+reproduces that; the default does what the Horovod wrapper is there for.)
+
+Chains are integrated only in the direction their coin selects: the reference's mask multiplies the other
+direction's outputs by exactly 0, so it contributes exactly 0 to every gradient."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .lattice import u1_observables
+
+METRICS = {'l1': 0, 'l2': 1, 'cos': 2, 'cos2': 3, 'cos_diff': 4}
+
+
+class GaugeTrainer:
+    def __init__(self, dynamics, lr_init=1e-3, lr_decay_steps=1000, lr_decay_rate=0.96, clip_value=None,
+                 metric='cos_diff', loss_scale=1., aux_weight=1., std_weight=1., charge_weight=1., dist=None,
+                 allreduce_grads=True, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        if metric not in METRICS:        # gauge_model.py:653-655
+            raise AttributeError(f"metric={metric}. Expected one of: 'l1', 'l2', 'cos', 'cos2', or 'cos_diff'.")
+        if dynamics.hmc:
+            raise ValueError("hmc=True dynamics have no trainable networks (gauge_model.py:913-918 builds the "
+                             "sampler only)")
+        if dynamics.network_arch != 'generic':
+            raise NotImplementedError("training is implemented for network_arch='generic'")
+        self.dynamics = dyn = dynamics
+        self.metric, self.loss_scale = metric, float(loss_scale)
+        self.weights = dict(aux_weight=float(aux_weight), std_weight=float(std_weight),
+                            charge_weight=float(charge_weight))
+        self.lr_init, self.lr_decay_steps, self.lr_decay_rate = float(lr_init), int(lr_decay_steps), float(lr_decay_rate)
+        self.clip_value = None if clip_value is None else float(clip_value)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist is not None else 1
+        self.allreduce_grads = bool(allreduce_grads)
+        self.global_step = 0
+        dev = dyn._device
+        self._nets = (dyn.position_fn, dyn.momentum_fn)
+        flats = [n.flat_params() for n in self._nets]
+        self._sizes = [f[0].numel() for f in flats]
+        n_all = sum(self._sizes) + 1
+        # one bucket: [xnet | vnet | eps]
+        self.grads = torch.zeros(n_all, dtype=torch.float32, device=dev)
+        self._m = torch.zeros_like(self.grads)
+        self._v = torch.zeros_like(self.grads)
+        self._eps_dev = torch.tensor([float(dyn.eps)], dtype=torch.float32, device=dev)
+        self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = _lib.Workspace()
+        self._grad_structs = []
+        off = 0
+        for (flat, views, offsets) in flats:
+            st = _lib.DenseGrads(**{k: self.grads.data_ptr() + 4 * (off + offsets[k][0]) for k in offsets})
+            self._grad_structs.append(st)
+            off += flat.numel()
+
+    # ---- views ----------------------------------------------------------------
+    def grad_views(self):
+        """{'xnet': {segment: tensor}, 'vnet': {...}, 'eps': tensor} over the flat gradient bucket."""
+        out, off = {}, 0
+        for name, net in zip(("xnet", "vnet"), self._nets):
+            flat, views, offsets = net.flat_params()
+            out[name] = {k: self.grads[off + a:off + b].view(views[k].shape) for k, (a, b) in offsets.items()}
+            off += flat.numel()
+        out["eps"] = self.grads[off:off + 1]
+        return out
+
+    def learning_rate(self):
+        """tf.train.exponential_decay(staircase=True) times the rank count (gauge_model.py:934-942)."""
+        return self.lr_init * self.lr_decay_rate ** (self.global_step // self.lr_decay_steps) * self.world
+
+    # ---- loss + gradients ----------------------------------------------------------
+    def calc_loss_and_grads(self, x, beta, z=None, draws_x=None, draws_z=None):
+        """gauge_model.py:799-830 -> (loss, x_out, accept_prob, x_dq); gradients land in self.grads.
+        draws_*: optional (momentum_f, momentum_b, coin, u) for the x and the z transition."""
+        dyn = self.dynamics
+        dev = dyn._device
+        T, X = dyn.lattice.time_size, dyn.lattice.space_size
+        x = dyn._x(x)
+        B, D = x.shape
+        z = dyn._normal((B, D)) if z is None else dyn._x(z)
+
+        def draw(d):
+            if d is None:
+                return dyn._normal((B, D)), dyn._normal((B, D)), dyn._uniform((B,)), dyn._uniform((B,))
+            return tuple(_lib.as_dev(a, dev) for a in d)
+        vf_x, vb_x, coin_x, u_x = draw(draws_x)
+        vf_z, vb_z, coin_z, _ = draw(draws_z)
+        coin = torch.cat([coin_x, coin_z])
+        fwd = coin > 0.5
+        x0 = torch.cat([x, z]).contiguous()
+        v0 = torch.where(fwd[:, None], torch.cat([vf_x, vf_z]), torch.cat([vb_x, vb_z])).contiguous()
+        dirs = (~fwd).to(torch.int32).contiguous()
+        R = 2 * B
+        xN, vN = torch.empty_like(x0), torch.empty_like(x0)
+        sld, p = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(2))
+        plan, L = dyn._plan(), _lib.lib()
+        ws, nb = self._ws.get(L.l2hmc_gauge_train_ws_bytes(C.byref(plan), R), dev)
+        s = _lib.stream_ptr()
+        _lib.check(L.l2hmc_gauge_train_forward(C.byref(plan), float(beta), x0.data_ptr(), v0.data_ptr(),
+                                               dirs.data_ptr(), R, xN.data_ptr(), vN.data_ptr(), sld.data_ptr(),
+                                               p.data_ptr(), ws, nb, s))
+        terms = torch.empty(B, dtype=torch.float32, device=dev)
+        dxN, dvN = torch.empty_like(x0), torch.empty_like(x0)
+        dld = torch.empty(R, dtype=torch.float32, device=dev)
+        w = self.weights
+        _lib.check(L.l2hmc_gauge_loss_backward(T, X, float(beta), x0.data_ptr(), xN.data_ptr(), vN.data_ptr(),
+                                               p.data_ptr(), B, METRICS[self.metric], self.loss_scale,
+                                               w['aux_weight'], w['std_weight'], w['charge_weight'],
+                                               1.0 / (B * self.world), terms.data_ptr(), dxN.data_ptr(),
+                                               dvN.data_ptr(), dld.data_ptr(), s))
+        n0, n1 = self._sizes
+        _lib.check(L.l2hmc_gauge_train_backward(C.byref(plan), float(beta), dirs.data_ptr(), R, dxN.data_ptr(),
+                                                dvN.data_ptr(), dld.data_ptr(), C.byref(self._grad_structs[0]),
+                                                C.byref(self._grad_structs[1]),
+                                                self.grads.data_ptr() + 4 * (n0 + n1), ws, nb, s))
+        buf = torch.stack([terms.sum(dtype=torch.float32),
+                           torch.full((), float(B), dtype=torch.float32, device=dev)])
+        if self.dist is not None:
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+            if self.allreduce_grads:
+                self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)
+        loss = buf[0] / buf[1]
+        px = p[:B]
+        x_prop = xN[:B]
+        x_out = torch.where((px > u_x)[:, None], x_prop, x)        # gauge_dynamics.py:244-257 (strict >)
+        q0 = u1_observables(x, T, X)["top_charge"]
+        q1 = u1_observables(x_out, T, X)["top_charge"]
+        x_dq = torch.abs(q0 - q1).to(torch.int32)                  # gauge_model.py:762-763
+        self.last_loss_terms, self.last_pz = terms, p[B:]
+        return loss, x_out, px, x_dq
+
+    # ---- optimiser --------------------------------------------------------------
+    def apply_gradients(self):
+        """clip_by_global_norm (if clip_value) + Adam on [xnet | vnet | eps]; bumps global_step."""
+        dyn, L, s = self.dynamics, _lib.lib(), _lib.stream_ptr()
+        lr = self.learning_rate()
+        self._adam_t = getattr(self, "_adam_t", 0) + 1
+        t = self._adam_t
+        lr_t = lr * (1. - self.beta2 ** t) ** 0.5 / (1. - self.beta1 ** t)
+        n0, n1 = self._sizes
+        gp, mp, vp = self.grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
+        segs = []
+        off = 0
+        for net in self._nets:
+            flat, _, offsets = net.flat_params()
+            segs.append((flat.data_ptr(), off, flat.numel(), offsets["b1"]))
+            off += flat.numel()
+        trainable_eps = bool(dyn.eps_trainable)
+        gnorm = None
+        if self.clip_value is not None:
+            for i, (_, o, n, tri) in enumerate(segs):
+                _lib.check(L.l2hmc_grad_sumsq(gp + 4 * o, n, tri[0], tri[1], self._gnorm.data_ptr(), int(i > 0), s))
+            if trainable_eps:
+                _lib.check(L.l2hmc_grad_sumsq(gp + 4 * off, 1, 0, 0, self._gnorm.data_ptr(), 1, s))
+            gnorm = self._gnorm.data_ptr()
+        clip = self.clip_value if self.clip_value is not None else 0.
+        for (wp, o, n, tri) in segs:
+            _lib.check(L.l2hmc_adam_step(wp, gp + 4 * o, mp + 4 * o, vp + 4 * o, n, lr_t, self.beta1, self.beta2,
+                                         self.epsilon, gnorm, clip, tri[0], tri[1], s))
+        if trainable_eps:
+            _lib.check(L.l2hmc_adam_step(self._eps_dev.data_ptr(), gp + 4 * off, mp + 4 * off, vp + 4 * off, 1, lr_t,
+                                         self.beta1, self.beta2, self.epsilon, gnorm, clip, 0, 0, s))
+            dyn.eps = self._eps_dev.detach().cpu().reshape(())     # the plan carries eps by value
+        for net in self._nets:
+            net.refresh_packed()
+        self.global_step += 1
+
+    def train_step(self, x, beta, **kw):
+        """One evaluation of the reference's train_op: (loss, x_out, px, x_dq)."""
+        out = self.calc_loss_and_grads(x, beta, **kw)
+        self.apply_gradients()
+        return out
+
+    def sync_weights(self):
+        """Bring the reference-layout layer tensors (state_dict / save_weights) up to date."""
+        for net in self._nets:
+            net.sync_reference_layout()

@@ -83,6 +83,7 @@ class _DenseSTQ:
                 raise ValueError(f"{n}: bad shape {tuple(c.shape)}")
             setattr(self, n, c)
         self._packed = None
+        self._flat = None
 
     def save_weights(self, path):
         """gauge_model.py:549-554 calls .save_weights on position_fn / momentum_fn."""
@@ -107,12 +108,60 @@ class _DenseSTQ:
             bhd=torch.stack([ls.bias, ltr.bias, lq.bias]).contiguous(),               # [3][D]
             coeff_s=cs.reshape(-1).contiguous(), coeff_q=cq.reshape(-1).contiguous())
 
+    SEGMENTS = ("w1_t", "wt", "b1", "wh_t", "bh", "whd_t", "bhd", "coeff_s", "coeff_q")
+
+    def flat_params(self):
+        """Training master copy: ONE flat fp32 buffer [w1_t | wt | b1 | wh_t | bh | whd_t | bhd | coeff_s |
+        coeff_q] whose slices are the buffers struct l2hmc_dense_net points at, so the optimiser is one
+        element-wise pass and the data-parallel all-reduce one bucket.  Returns (flat, views, offsets); after
+        this call pack() reads the flat buffer, and the reference-layout layer tensors are refreshed by
+        sync_reference_layout()."""
+        if getattr(self, "_flat", None) is None:
+            bufs = self._pack_tensors()
+            flat = torch.cat([bufs[k].reshape(-1) for k in self.SEGMENTS])
+            views, offsets, off = {}, {}, 0
+            for k in self.SEGMENTS:
+                n = bufs[k].numel()
+                views[k] = flat[off:off + n].view(bufs[k].shape)
+                offsets[k] = (off, off + n)
+                off += n
+            self._flat = (flat, views, offsets)
+            self._packed = None
+        return self._flat
+
+    def refresh_packed(self):
+        """After the flat buffer changed: rebuild the fragment-ordered image of the fused kernel."""
+        if self._packed is not None and "packed" in self._packed[1]:
+            st, bufs = self._packed
+            _lib.check(_lib.lib().l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr()))
+
+    def sync_reference_layout(self):
+        """Flat training buffer -> reference-layout layer tensors (state_dict / save_weights read those).
+        The three first-layer biases share one packed bias and identical gradients; each takes a third of
+        the packed bias's movement, which is what Adam does to them in the reference."""
+        if getattr(self, "_flat", None) is None:
+            return
+        v = self._flat[1]
+        la, lb, lt, lh, ls, ltr, lq = self._layers()
+        Ka = la.kernel.shape[0]
+        delta = (v["b1"] - (la.bias + lb.bias + lt.bias)) / 3.
+        la.bias, lb.bias, lt.bias = la.bias + delta, lb.bias + delta, lt.bias + delta
+        la.kernel = v["w1_t"][:, :Ka].t().contiguous()
+        lb.kernel = v["w1_t"][:, Ka:].t().contiguous()
+        lt.kernel = v["wt"].clone()
+        lh.kernel, lh.bias = v["wh_t"].t().contiguous(), v["bh"].clone()
+        for i, layer in enumerate((ls, ltr, lq)):
+            layer.kernel, layer.bias = v["whd_t"][i].t().contiguous(), v["bhd"][i].clone()
+        cs, cq = self._coeff_names
+        setattr(self, cs, v["coeff_s"].reshape(1, -1).clone())
+        setattr(self, cq, v["coeff_q"].reshape(1, -1).clone())
+
     def pack(self):
         """struct l2hmc_dense_net over device buffers (kept alive here); rebuilt after load_state()."""
         if self._packed is None:
             la, lb, lt, lh, ls, ltr, lq = self._layers()
             Ka, Kb, H, D = la.kernel.shape[0], lb.kernel.shape[0], lh.kernel.shape[0], ls.kernel.shape[1]
-            bufs = self._pack_tensors()
+            bufs = dict(self._flat[1]) if getattr(self, "_flat", None) is not None else self._pack_tensors()
             st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0, packed=None,
                                **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
             L = _lib.lib()

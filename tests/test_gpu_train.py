@@ -1,0 +1,197 @@
+"""GPU parity of the training path: gradients of the loss with respect to every weight and
+the step size, through the C ABI, against torch.autograd on the float64 restatement (oracle/torch_ref.py).
+
+Tolerance: the forward path meets north_star's 1e-5; gradients are sums of ~1e5 fp32 products through up to
+4N chained network calls, so they are compared per tensor in the max norm relative to the tensor's own largest
+entry at 2e-4 (measured: 1e-6..3e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.torch_ref import TorchGaugeModel
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_G = 2e-4
+
+
+def _setup(L, N, eps, B, regime, metric='cos_diff', seed=7):
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    T = X = L
+    D = 2 * T * X
+    xp, vp = H.gauge_weights(T, X, regime=regime)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    tr = GaugeTrainer(dyn, metric=metric, lr_init=1e-3)
+    tm = TorchGaugeModel(T, X, N, eps, orc.mask, xp, vp)
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 2 * np.pi, (B, D))
+    z = rng.standard_normal((B, D))
+    dx = (rng.standard_normal((B, D)), rng.standard_normal((B, D)), rng.uniform(size=B), rng.uniform(size=B))
+    dz = (rng.standard_normal((B, D)), rng.standard_normal((B, D)), rng.uniform(size=B), rng.uniform(size=B))
+    return tr, tm, x, z, dx, dz
+
+
+def _ref_grads(tm, x, z, dx, dz, beta, metric, **w):
+    tt = lambda a: torch.tensor(a, dtype=torch.float64)
+    loss, terms = tm.loss(tt(x), tt(z), beta, tuple(map(tt, dx)), tuple(map(tt, dz)), metric=metric, **w)
+    loss.backward()
+    return float(loss.detach()), terms.detach().numpy()
+
+
+def _packed_ref(net):
+    """autograd gradients of one network, rearranged into the library's k-contiguous layout."""
+    g = {k: v.grad.numpy() for k, v in net.items()}
+    return {
+        "w1_t": np.concatenate([g['v_layer/W'], g['x_layer/W']], axis=0).T,
+        "wt": g['t_layer/W'],
+        "b1": g['v_layer/b'],
+        "wh_t": g['h_layer/W'].T,
+        "bh": g['h_layer/b'],
+        "whd_t": np.stack([g['scale_layer/W'].T, g['translation_layer/W'].T, g['transformation_layer/W'].T]),
+        "bhd": np.stack([g['scale_layer/b'], g['translation_layer/b'], g['transformation_layer/b']]),
+        "coeff_s": g['coeff_scale'].reshape(-1),
+        "coeff_q": g['coeff_transformation'].reshape(-1),
+    }
+
+
+def _compare(tr, tm, tol=TOL_G):
+    gv = tr.grad_views()
+    worst = {}
+    for name, net in (("xnet", tm.xnet), ("vnet", tm.vnet)):
+        ref = _packed_ref(net)
+        # the three first-layer biases have identical gradients in the reference graph
+        assert np.allclose(net['v_layer/b'].grad.numpy(), net['x_layer/b'].grad.numpy())
+        assert np.allclose(net['v_layer/b'].grad.numpy(), net['t_layer/b'].grad.numpy())
+        for k, want in ref.items():
+            got = gv[name][k].cpu().numpy().astype(np.float64)
+            scale = np.abs(want).max()
+            assert scale > 0, (name, k)
+            worst[f"{name}.{k}"] = float(np.abs(got - want).max() / scale)
+    want = float(tm.eps.grad)
+    worst["eps"] = abs(float(gv["eps"][0]) - want) / abs(want)
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, f"gradient mismatch: {bad}\nall: {worst}"
+    return worst
+
+
+@pytest.mark.parametrize("L,N,eps,B,regime", [
+    (4, 3, 0.2, 6, "mild"),
+    (4, 2, 0.15, 37, "stress"),       # ragged batch, strong S/Q
+    (8, 2, 0.1, 16, "mild"),          # benchmark widths D=128, H=512
+])
+def test_loss_gradients_match_autograd(L, N, eps, B, regime):
+    tr, tm, x, z, dx, dz = _setup(L, N, eps, B, regime)
+    beta = 2.5
+    loss, x_out, px, x_dq = tr.calc_loss_and_grads(x, beta, z=z, draws_x=dx, draws_z=dz)
+    want_loss, want_terms = _ref_grads(tm, x, z, dx, dz, beta, 'cos_diff')
+    # per-chain terms are differences of O(1/eps_loss = 1e3) quantities: absolute tolerance on that scale
+    np.testing.assert_allclose(tr.last_loss_terms.cpu().numpy(), want_terms, rtol=2e-4,
+                               atol=1e-5 * max(1., np.abs(want_terms).max()))
+    assert abs(float(loss) - want_loss) <= 2e-4 * max(1., abs(want_loss))
+    _compare(tr, tm)
+
+
+@pytest.mark.parametrize("metric", ['l1', 'l2', 'cos', 'cos2'])
+def test_loss_gradients_other_metrics_and_weights(metric):
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, 9, "mild", metric=metric)
+    tr.loss_scale = 0.7
+    tr.weights = dict(aux_weight=0.5, std_weight=1.3, charge_weight=0.8)
+    tr.calc_loss_and_grads(x, 3.0, z=z, draws_x=dx, draws_z=dz)
+    _ref_grads(tm, x, z, dx, dz, 3.0, metric, loss_scale=0.7, aux_weight=0.5, std_weight=1.3, charge_weight=0.8)
+    _compare(tr, tm)
+
+
+def test_taped_forward_equals_sampling_path():
+    """The taped forward pass must produce what the sampling kernels produce (same C-ABI outputs)."""
+    import ctypes as C
+    from l2hmc_amd import _lib
+    tr, tm, x, z, dx, dz = _setup(8, 3, 0.2, 12, "mild")
+    dyn = tr.dynamics
+    dev = dyn._device
+    R, D = 24, 128
+    x0 = _lib.as_dev(np.concatenate([x, z]), dev)
+    v0 = _lib.as_dev(np.concatenate([dx[0], dz[0]]), dev)
+    dirs = torch.tensor([0, 1] * 12, dtype=torch.int32, device=dev)
+    plan, L = dyn._plan(), _lib.lib()
+    outs = []
+    for mode in ("train", "sample"):
+        xo, vo = torch.empty_like(x0), torch.empty_like(x0)
+        sld, p = torch.empty(R, device=dev), torch.empty(R, device=dev)
+        if mode == "train":
+            ws, nb = tr._ws.get(L.l2hmc_gauge_train_ws_bytes(C.byref(plan), R), dev)
+            _lib.check(L.l2hmc_gauge_train_forward(C.byref(plan), 2.0, x0.data_ptr(), v0.data_ptr(), dirs.data_ptr(), R,
+                                                   xo.data_ptr(), vo.data_ptr(), sld.data_ptr(), p.data_ptr(), ws, nb,
+                                                   _lib.stream_ptr()))
+        else:
+            ws, nb = dyn._ws.get(L.l2hmc_gauge_ws_bytes(C.byref(plan), R), dev)
+            _lib.check(L.l2hmc_gauge_trajectory(C.byref(plan), 2.0, x0.data_ptr(), v0.data_ptr(), dirs.data_ptr(), R,
+                                                xo.data_ptr(), vo.data_ptr(), sld.data_ptr(), p.data_ptr(), ws, nb,
+                                                _lib.stream_ptr()))
+        outs.append([t.cpu().numpy() for t in (xo, vo, sld, p)])
+    for a, b in zip(*outs):
+        assert H.relerr(a, b) <= 2e-5
+
+
+def test_adam_matches_reference_update_rule():
+    """tf.train.AdamOptimizer's update (epsilon-hat form) on the flat buffers, with clip_by_global_norm, for 3
+    steps of constant synthetic gradients; the packed first-layer bias moves three times as far."""
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, 4, "mild")
+    tr.clip_value = 0.5
+    dyn = tr.dynamics
+    flats = [n.flat_params() for n in tr._nets]
+    w0 = [f[0].clone() for f in flats]
+    eps0 = float(dyn.eps)
+    g = torch.randn_like(tr.grads) * 0.01
+    # numpy restatement
+    n0, n1 = tr._sizes
+    gn = g.cpu().numpy().astype(np.float64)
+    tri = np.ones_like(gn)
+    off = 0
+    for f in flats:
+        a, b = f[2]["b1"]
+        tri[off + a:off + b] = 3.
+        off += f[0].numel()
+    norm = np.sqrt(np.sum(tri * gn * gn))
+    gc = gn * 0.5 / max(norm, 0.5)
+    m = np.zeros_like(gn); v = np.zeros_like(gn)
+    w = np.concatenate([w0[0].cpu().numpy(), w0[1].cpu().numpy(), [eps0]]).astype(np.float64)
+    for t in range(1, 4):
+        tr.grads.copy_(g)
+        lr = tr.learning_rate()
+        tr.apply_gradients()
+        m = 0.9 * m + 0.1 * gc
+        v = 0.999 * v + 0.001 * gc * gc
+        lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        w = w - tri * lr_t * m / (np.sqrt(v) + 1e-8)
+    got = np.concatenate([flats[0][0].cpu().numpy(), flats[1][0].cpu().numpy(), [float(dyn.eps)]])
+    np.testing.assert_allclose(got, w, rtol=2e-5, atol=2e-7)
+    assert tr.global_step == 3
+
+
+def test_training_reduces_loss_and_sampler_sees_new_weights():
+    """A few train steps on a fixed batch lower the loss; the fused sampling kernel then runs with the updated
+    weights (its packed image is rebuilt) and agrees with the layered path."""
+    tr, tm, x, z, dx, dz = _setup(8, 3, 0.15, 64, "init")
+    tr.lr_init = 1e-4      # measured: monotone decrease -122.5 -> -145.4 over 8 steps on this batch
+    losses = []
+    for _ in range(6):
+        loss, *_ = tr.train_step(x, 2.0, z=z, draws_x=dx, draws_z=dz)
+        losses.append(float(loss))
+    assert np.isfinite(losses).all()
+    assert losses[1] < losses[0] and losses[-1] < losses[1], losses
+    dyn = tr.dynamics
+    xin, v0f, v0b, coin, u = H.gauge_inputs(64, 128)
+    dyn.fused = True
+    a = dyn.apply_transition(xin, 2.0, v0f, v0b, coin, u)
+    dyn.fused = False
+    b = dyn.apply_transition(xin, 2.0, v0f, v0b, coin, u)
+    for s, t in zip(a, b):
+        assert H.relerr(s.cpu().numpy(), t.cpu().numpy()) <= 5e-5
+    # reference-layout tensors follow the flat buffer
+    before = dyn.position_fn.h_layer.kernel.clone()
+    tr.sync_weights()
+    assert not torch.equal(before, dyn.position_fn.h_layer.kernel)
+    np.testing.assert_array_equal(dyn.position_fn.h_layer.kernel.t().cpu().numpy(),
+                                  dyn.position_fn.flat_params()[1]["wh_t"].cpu().numpy())
