@@ -41,12 +41,19 @@ def net_macs(D, H):
     return 2 * D * H + 2 * H + H * H + 3 * H * D
 
 
-def build_dynamics(batch, both_directions=True):
-    from tests import helpers as H
-    xp, vp = H.gauge_weights(L, L, seed=106, regime="init", hidden_mult=HID_MULT)
-    masks = H.gauge_oracle(L, L, N_LF, EPS, xp, vp).mask
-    dyn = H.gauge_hip(L, L, N_LF, EPS, xp, vp, masks, batch, both_directions=both_directions)
-    return dyn, xp, vp, masks
+def build_dynamics(batch, both_directions=True, arch='generic'):
+    """The product's own constructor (reference initialisation, generic_net.py:39-90) under fixed NumPy seeds;
+    returns the weights/masks as NumPy too, for the cpu_baseline leg."""
+    import l2hmc_amd as la
+    np.random.seed(106)
+    lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=batch, rand=False)
+    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=EPS, hmc=False, network_arch=arch, num_steps=N_LF,
+                           eps_trainable=True, data_format='channels_last', both_directions=both_directions)
+    if arch != 'generic':
+        return dyn, None, None, None
+    xp = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dyn.position_fn.state_dict().items()}
+    vp = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dyn.momentum_fn.state_dict().items()}
+    return dyn, xp, vp, dyn.mask.cpu().numpy()
 
 
 def main():
@@ -59,6 +66,7 @@ def main():
     ap.add_argument("--layered", action="store_true", help="use the layer-by-layer kernels (no fused trajectory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,9 +195,8 @@ def main():
 
     # ---- the same workload with the reference's CLI-default architecture (conv3D, gauge_model.py:2307) ----
     if rank == 0 and world == 1 and not args.no_roofline:
-        from tests import helpers as H
-        cxp, cvp = H.conv_weights(L, L, seed=106, regime="init")
-        cdyn = H.gauge_hip(L, L, N_LF, EPS, cxp, cvp, masks, BATCH, both_directions=both, arch='conv3D')
+        cdyn = build_dynamics(BATCH, both, arch='conv3D')[0]
+        cdyn.set_masks(masks)
         csmp = GaugeSampler(cdyn)
         xc = x.clone()
         for _ in range(3):
@@ -202,6 +209,50 @@ def main():
         tcd = (time.perf_counter() - tc0) / 20
         out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
                                         "chain_leapfrog_steps_per_s": BATCH * N_LF / tcd}
+
+    # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
+    #      takes part because the gradient bucket is all-reduced (f1/f2) ----
+    if not args.no_train:
+        from l2hmc_amd.gauge_trainer import GaugeTrainer
+        ok, err, tr = 1, "", None
+        try:
+            tdyn = build_dynamics(BATCH, both)[0]
+            tdyn._seed = 2000 + rank
+            tr = GaugeTrainer(tdyn, lr_init=1e-4, dist=dist)
+            saved, tr.dist = tr.dist, None
+            tr.train_step(x, BETA)                # local rehearsal: no collective yet
+            tr.dist = saved
+            torch.cuda.synchronize()
+        except Exception as e:                    # noqa: BLE001 -- reported in the JSON line
+            ok, err = 0, repr(e)
+        if dist is not None:                      # only enter the collective steps if every rank can
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) if ok else 0
+        if ok:
+            nt = 10
+            tr.train_step(x, BETA)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            tt0 = time.perf_counter()
+            for _ in range(nt):
+                loss = tr.train_step(x, BETA)[0]
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            ttd = (time.perf_counter() - tt0) / nt
+            if dist is not None:
+                t = torch.tensor([ttd], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ttd = float(t.item())
+            out["config"]["train_step"] = {
+                "what": "loss + hand-written reverse pass + gradient all-reduce + Adam, 2048 x-chains and 2048 "
+                        "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
+                "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
+                "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss)}
+        else:
+            out["config"]["train_step"] = {"error": err or "another rank failed"}
 
     # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

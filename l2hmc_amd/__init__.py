@@ -8,4 +8,5 @@ from .dynamics import Dynamics  # noqa: F401
 from .sampler import propose, tf_accept  # noqa: F401
 from .distributions import GMM, Gaussian, gen_ring, quadratic_gaussian  # noqa: F401
 from .gauge_sampler import GaugeSampler  # noqa: F401
+from .gauge_trainer import GaugeTrainer  # noqa: F401
 from . import stats  # noqa: F401

@@ -439,9 +439,13 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     const bool big = t128 >= 512;
     a.mtiles = (int)ceil_div(a.rows, big ? 128 : 64);
     const dim3 grid(a.mtiles * a.ntiles);
+    const bool deep3 = !big && (a.K % 64 == 0) && a.mtiles * a.ntiles <= 256;
     if (big) {
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<128, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<128, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else if (deep3) {
+      if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 64>), grid, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 64>), grid, dim3(kGemmThreads), 0, stream, a);
     } else {
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);

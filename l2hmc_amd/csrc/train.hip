@@ -380,51 +380,88 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     }
 }
 
-// out[i] = sum_s part[s][i]  (fixed order)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t count,
-                                       float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+// out[i] = sum_s part[s][i]  (fixed order: four interleaved partial sums, then their sum)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t count,
+                                                              float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + il;
   float t = 0.f;
-  for (int s = 0; s < S; ++s) t += part[(size_t)s * count + i];
-  out[i] = t;
+  if (i < count) {
+#pragma unroll 8
+    for (int s = sl; s < S; s += 4) t += part[(size_t)s * count + i];
+  }
+  red[sl][il] = t;
+  __syncthreads();
+  if (sl == 0 && i < count) out[i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
 // column sums of a taped [calls * rows][n] array (bias gradients), optionally also weighted by the
 // (cos, sin) time input of each (call, row) -- the t_layer kernel's gradient (generic_net.py:131).
-// grid (ceil(n/256), S); part: [S][3][n] (plain, cos-weighted, sin-weighted)
+// HBM-bound: every thread streams 16-byte pieces of consecutive rows; a workgroup covers up to 1024
+// columns (blockIdx.x) of one row chunk (blockIdx.y).  part: [S][3][n] (plain, cos-, sin-weighted).
+constexpr int kColsumMaxS = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t Rt, int n,
                                                      int64_t rows, int nsteps, const int* __restrict__ dir,
                                                      int timed, int64_t chunk, float* __restrict__ part) {
-  extern __shared__ float tab[];   // [nsteps][2] (cos, sin)
+  extern __shared__ float sm[];    // [nsteps][2] (cos, sin), then the cross-row reduction scratch
+  float* tab = sm;
+  float* red = sm + 2 * nsteps;
   if (timed) {
     for (int i = threadIdx.x; i < nsteps; i += blockDim.x) {
       const float ang = (float)(2.0 * M_PI) * (float)i / (float)nsteps;
       tab[2 * i] = cosf(ang);
       tab[2 * i + 1] = sinf(ang);
     }
-    __syncthreads();
   }
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= n) return;
+  __syncthreads();
+  const int c0 = blockIdx.x * 1024;
+  const int nc4 = (n - c0 < 1024 ? n - c0 : 1024) / 4;   // 16-byte pieces per row in this column group
+  const int rpp = 256 / nc4 > 0 ? 256 / nc4 : 1;          // rows per pass
+  const int rl = threadIdx.x / nc4, cl = threadIdx.x - rl * nc4;
+  const bool active = rl < rpp;
   const int64_t rb = (int64_t)blockIdx.y * chunk;
   const int64_t re = rb + chunk < Rt ? rb + chunk : Rt;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int64_t rr = rb; rr < re; ++rr) {
-    const float v = src[rr * n + col];
-    s0 += v;
-    if (timed) {
-      const int64_t call = rr / rows, row = rr - call * rows;
-      const int step = (int)(call >> 1);
-      const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
-      s1 += tab[2 * i] * v;
-      s2 += tab[2 * i + 1] * v;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+  if (active) {
+#pragma unroll 4
+    for (int64_t rr = rb + rl; rr < re; rr += rpp) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + rr * n + c0 + cl * 4);
+      s0 += v;
+      if (timed) {
+        const int64_t call = rr / rows, row = rr - call * rows;
+        const int step = (int)(call >> 1);
+        const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
+        s1 += tab[2 * i] * v;
+        s2 += tab[2 * i + 1] * v;
+      }
+    }
+    float* o = red + (size_t)(rl * nc4 + cl) * 12;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = s0[e];
+      o[4 + e] = s1[e];
+      o[8 + e] = s2[e];
     }
   }
-  float* o = part + (size_t)blockIdx.y * 3 * n;
-  o[col] = s0;
-  o[n + col] = s1;
-  o[2 * n + col] = s2;
+  __syncthreads();
+  if (threadIdx.x < nc4) {
+    float* o = part + (size_t)blockIdx.y * 3 * n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < rpp; ++q) {
+        const float* r = red + (size_t)(q * nc4 + threadIdx.x) * 12;
+        t0 += r[e];
+        t1 += r[4 + e];
+        t2 += r[8 + e];
+      }
+      const int col = c0 + threadIdx.x * 4 + e;
+      o[col] = t0;
+      o[n + col] = t1;
+      o[2 * n + col] = t2;
+    }
+  }
 }
 
 // out[c][r] = in[r][c]
@@ -652,10 +689,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 struct NetTape {
   float *in, *h1, *h2, *stq, *st, *d1, *d2, *dout;   // [calls][rows][.]
   float *dcs_part, *dcq_part;                         // [nblk][D]
+  float *w1_n, *wh_n, *whd_n;                         // weights transposed for the backward-data products
 };
 struct TrainWs {
   NetTape x, v;
-  float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *wT, *part, *eps_part, *xw, *vw;
+  float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *part, *eps_part;
   size_t bytes;
 };
 
@@ -681,7 +719,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   };
   const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
   NetTape* tapes[2] = {&w.x, &w.v};
-  size_t wt_max = 0, part_max = 0;
+  size_t part_max = 0;
   for (int k = 0; k < 2; ++k) {
     const int H = nets[k]->H;
     NetTape& t = *tapes[k];
@@ -696,7 +734,9 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     t.dout = take(cr * 3 * D);
     t.dcs_part = take((size_t)upd_blocks(rows) * D);
     t.dcq_part = take((size_t)upd_blocks(rows) * D);
-    wt_max = smax(wt_max, smax((size_t)2 * D * H, smax((size_t)H * H, (size_t)3 * D * H)));
+    t.w1_n = take((size_t)2 * D * H);
+    t.wh_n = take((size_t)H * H);
+    t.whd_n = take((size_t)3 * D * H);
     // split-k partials of the three weight-gradient products and the column sums
     const int64_t R = (int64_t)cr;
     auto need = [&](int M, int N) {
@@ -704,7 +744,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
       return (size_t)tn_splits(mt, nt, R) * M * N;
     };
     part_max = smax(part_max, smax(need(H, 2 * D), smax(need(H, H), need(3 * D, H))));
-    part_max = smax(part_max, (size_t)65 * 3 * hmax(H, 3 * D));
+    part_max = smax(part_max, (size_t)(kColsumMaxS + 1) * 3 * hmax(H, 3 * D));
   }
   w.mask_inv = take((size_t)p->num_steps * D);
   w.ld = take(rows);
@@ -712,11 +752,8 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   w.g = take((size_t)rows * D);
   w.dg = take((size_t)rows * D);
   w.din = take((size_t)rows * 2 * D);
-  w.wT = take(wt_max);
   w.part = take(part_max);
   w.eps_part = take(upd_blocks(rows));
-  w.xw = take((size_t)rows * D);
-  w.vw = take((size_t)rows * D);
   w.bytes = off;
   return w;
 }
@@ -790,37 +827,27 @@ static int call_backward_data(const l2hmc_dense_net* net, const NetTape& t, int 
                               hipStream_t s) {
   const int D = net->D, H = net->H;
   const size_t cr = (size_t)call * rows;
-  const dim3 tb(256);
   // d2 = (dout . Whd) gated by h2 > 0:   B operand [H][3D] = transpose of whd_t [3D][H]
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(3 * D, 32)), tb, 0, s,
-                     net->whd_t, 3 * D, H, w.wT);
-  L2HMC_CHECK_LAUNCH("transpose");
   GemmReluArgs g2{};
   g2.kind = 3;
   g2.A1 = t.dout + cr * 3 * D; g2.lda1 = 3 * D; g2.K1 = 3 * D; g2.K = 3 * D;
-  g2.Wt = w.wT; g2.N = H;
+  g2.Wt = t.whd_n; g2.N = H;
   g2.gate = t.h2 + cr * H; g2.ldg = H;
   g2.out = t.d2 + cr * H; g2.ldo = H; g2.rows = rows;
   if (int e = launch_gemm_relu(g2, s)) return e;
   // d1 = (d2 . Wh) gated by h1 > 0:      B operand [H_in][H_out] = transpose of wh_t [out][in]
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
-                     net->wh_t, H, H, w.wT);
-  L2HMC_CHECK_LAUNCH("transpose");
   GemmReluArgs g1{};
   g1.kind = 3;
   g1.A1 = t.d2 + cr * H; g1.lda1 = H; g1.K1 = H; g1.K = H;
-  g1.Wt = w.wT; g1.N = H;
+  g1.Wt = t.wh_n; g1.N = H;
   g1.gate = t.h1 + cr * H; g1.ldg = H;
   g1.out = t.d1 + cr * H; g1.ldo = H; g1.rows = rows;
   if (int e = launch_gemm_relu(g1, s)) return e;
   // din = d1 . W1:                        B operand [2D][H] = transpose of w1_t [H][2D]
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(2 * D, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
-                     net->w1_t, H, 2 * D, w.wT);
-  L2HMC_CHECK_LAUNCH("transpose");
   GemmReluArgs g0{};
   g0.kind = 4;
   g0.A1 = t.d1 + cr * H; g0.lda1 = H; g0.K1 = H; g0.K = H;
-  g0.Wt = w.wT; g0.N = 2 * D;
+  g0.Wt = t.w1_n; g0.N = 2 * D;
   g0.out = w.din; g0.ldo = 2 * D; g0.rows = rows;
   return launch_gemm_relu(g0, s);
 }
@@ -836,7 +863,7 @@ static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, floa
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.mt * a.nt * splits), dim3(256), 0, s, a);
   L2HMC_CHECK_LAUNCH("gemm_tn");
   const int64_t count = (int64_t)M * N;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, w.part, splits,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(count, 64)), dim3(256), 0, s, w.part, splits,
                      count, out);
   L2HMC_CHECK_LAUNCH("reduce_partials");
   return L2HMC_OK;
@@ -844,15 +871,16 @@ static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, floa
 
 static int colsum(const float* src, int64_t Rt, int n, int64_t rows, int nsteps, const int* dir, int timed,
                   float* out_plain, float* out_cos, float* out_sin, const TrainWs& w, hipStream_t s) {
-  const int S = (int)hmin(64, imax64(1, Rt / 64));
+  L2HMC_REQUIRE(n % 4 == 0, "colsum: width %d must be a multiple of 4", n);
+  const int S = (int)hmin(kColsumMaxS, imax64(1, Rt / 128));
   const int64_t chunk = ceil_div(Rt, S);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), sizeof(float) * 2 * nsteps, s,
-                     src, Rt, n, rows, nsteps, dir, timed, chunk, w.part);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 1024), S), dim3(256),
+                     sizeof(float) * (2 * nsteps + 256 * 12), s, src, Rt, n, rows, nsteps, dir, timed, chunk, w.part);
   L2HMC_CHECK_LAUNCH("colsum");
   // partials are [S][3][n]: reduce each plane with stride 3n
   // (reduce_partials_kernel sums part[s * count + i]; use count = 3n and a scratch of 3n, then split)
   float* tmp = w.part + (size_t)S * 3 * n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(3 * n, 256)), dim3(256), 0, s, w.part, S,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(3 * n, 64)), dim3(256), 0, s, w.part, S,
                      (int64_t)3 * n, tmp);
   L2HMC_CHECK_LAUNCH("reduce_partials");
   if (hipMemcpyAsync(out_plain, tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
@@ -957,6 +985,22 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     set_error("train_backward: memset failed");
     return L2HMC_ERR_HIP;
   }
+  {
+    // weights as the backward-data products read them (k = output unit contiguous), once per pass
+    const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
+    const NetTape* tapes[2] = {&w.x, &w.v};
+    for (int k = 0; k < 2; ++k) {
+      const int H = nets[k]->H;
+      const dim3 tb(256);
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(3 * D, 32)), tb, 0, s,
+                         nets[k]->whd_t, 3 * D, H, tapes[k]->whd_n);
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
+                         nets[k]->wh_t, H, H, tapes[k]->wh_n);
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(2 * D, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
+                         nets[k]->w1_t, H, 2 * D, tapes[k]->w1_n);
+      L2HMC_CHECK_LAUNCH("transpose");
+    }
+  }
   const unsigned rgrid = (unsigned)ceil_div(rows, 4);
   const size_t vlds = sizeof(float) * 4 * (size_t)(2 * D + D / 2);
   L2HMC_REQUIRE(vlds <= 160 * 1024, "train_backward: lattice too large for the force-Hessian kernel's LDS");
@@ -1020,9 +1064,9 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
     if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
     if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, t.dcs_part,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcs_part,
                        (int)nblk, (int64_t)D, g->coeff_s);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 256)), dim3(256), 0, s, t.dcq_part,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcq_part,
                        (int)nblk, (int64_t)D, g->coeff_q);
     L2HMC_CHECK_LAUNCH("reduce_partials");
   }

@@ -1,0 +1,36 @@
+"""Worker of test_data_parallel_gradients_equal_full_batch: one rank of a data-parallel training step.
+Each rank owns a contiguous shard of the chains (l2hmc_amd.dist.shard_bounds) and a replica of the weights;
+after GaugeTrainer's single all-reduce every rank holds the full-batch gradient.  Rank 0 saves it."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.test_gpu_train import _setup  # noqa: E402
+from l2hmc_amd.dist import shard_bounds  # noqa: E402
+
+
+def main():
+    out, B = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)            # the test box has one GPU: both ranks share it, gloo carries the exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, B, "mild")
+    lo, hi = shard_bounds(B, world, rank)
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    tr = GaugeTrainer(tr.dynamics, dist=dist)
+    loss, *_ = tr.calc_loss_and_grads(x[lo:hi], 2.5, z=z[lo:hi], draws_x=tuple(a[lo:hi] for a in dx),
+                                      draws_z=tuple(a[lo:hi] for a in dz))
+    tr.apply_gradients()
+    if rank == 0:
+        np.savez(out, grads=tr.grads.cpu().numpy(), loss=float(loss), lr=tr.learning_rate(),
+                 w=tr._nets[0].flat_params()[0].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,3 +195,34 @@ def test_training_reduces_loss_and_sampler_sees_new_weights():
     assert not torch.equal(before, dyn.position_fn.h_layer.kernel)
     np.testing.assert_array_equal(dyn.position_fn.h_layer.kernel.t().cpu().numpy(),
                                   dyn.position_fn.flat_params()[1]["wh_t"].cpu().numpy())
+
+
+def test_data_parallel_gradients_equal_full_batch(tmp_path):
+    """two ranks, each with half of the chains, one all-reduce -> the full-batch gradient and
+    loss.  (Both ranks share the test box's single GPU; the exchange runs over gloo.  On a multi-GPU node the
+    same code path runs with backend "nccl" = RCCL.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    B = 10
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, B, "mild")
+    loss, *_ = tr.calc_loss_and_grads(x, 2.5, z=z, draws_x=dx, draws_z=dz)
+    full = tr.grads.cpu().numpy().copy()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dp_train_worker.py"),
+                                       out, str(B)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    with np.load(out) as f:
+        got, got_loss, lr = f["grads"], float(f["loss"]), float(f["lr"])
+    assert abs(got_loss - float(loss)) <= 1e-5 * max(1., abs(float(loss)))
+    scale = np.abs(full).max()
+    assert np.abs(got - full).max() <= 2e-5 * scale      # summation order differs between 1 and 2 shards
+    assert lr == pytest.approx(2 * tr.learning_rate())    # gauge_model.py:942: lr * hvd.size()
