@@ -23,6 +23,7 @@
 // 16-row ones).  Tile ids are remapped so tiles sharing activation rows land on
 // one XCD (shared L2).
 #include "stq_dense.h"
+#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -50,13 +51,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // KIND 2: hidden layer (single source, plain bias)
 // KIND 3: backward-data through a relu layer: out = (A . Wt^T) where gate > 0, else 0   (no bias)
 // KIND 4: plain product out = A . Wt^T
-template <int BM, int KIND, int BK>
+template <int BM, int KIND, int BK, int BN = 128>
 __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
-  constexpr int BN = 128;
   constexpr int CPR = BK / 4;              // 16-byte chunks per staged row
   constexpr int LDK = BK + 4;              // rows of 36 / 68 floats: an odd number of 16-B slots => conflict-free b128 reads
   constexpr int MT = BM / 64;              // 32x32 tiles per wave along M (wave grid 2 x 2)
-  constexpr int NT = 2;                    // wave covers 64 columns
+  constexpr int WN = BN / 2;               // columns per wave: 64 (BN = 128) or 32 (BN = 64)
+  constexpr int NT = WN / 32;
   constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
   constexpr int B_CH = BN * (BK / 4) / kGemmThreads;
   constexpr int STAGE = (BM + BN) * LDK;   // one A|B buffer pair
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
     const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + half * 4;
-    const float* bs = lds + cur * STAGE + BM * LDK + (wn * 64 + r) * LDK + half * 4;
+    const float* bs = lds + cur * STAGE + BM * LDK + (wn * WN + r) * LDK + half * 4;
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       f32x4 af[MT], bf[NT];
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
   // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + r;
+    const int col = n0 + wn * WN + j * 32 + r;
     const bool cok = col < p.N;
     const float bj = (KIND <= 2 && cok) ? p.bias[col] : 0.f;
     const float w0 = (KIND == 1 && cok && p.wt0) ? p.wt0[col] : 0.f;
@@ -413,6 +414,14 @@ int dense_net_supported(const l2hmc_dense_net* n) {
          (n->H % BK) == 0;
 }
 
+static bool narrow_tiles() {
+  static const int mode = [] {
+    const char* e = getenv("L2HMC_GEMM_NARROW");
+    return e ? atoi(e) : 1;
+  }();
+  return mode != 0;
+}
+
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.K % BK == 0 && a.K1 % BK == 0 && a.K1 <= a.K, "gemm: K=%d K1=%d must be multiples of %d",
                 a.K, a.K1, BK);
@@ -440,7 +449,12 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     a.mtiles = (int)ceil_div(a.rows, big ? 128 : 64);
     const dim3 grid(a.mtiles * a.ntiles);
     const bool deep3 = !big && (a.K % 64 == 0) && a.mtiles * a.ntiles <= 256;
-    if (big) {
+    if (deep3 && narrow_tiles()) {
+      a.ntiles = (int)ceil_div(a.N, 64);
+      const dim3 g64(a.mtiles * a.ntiles);
+      if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
+    } else if (big) {
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<128, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<128, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
     } else if (deep3) {
@@ -466,7 +480,14 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   } else {
     a.mtiles = (int)ceil_div(a.rows, 64);
     const dim3 grid(a.mtiles * a.ntiles);
-    if (deep) {
+    if (deep && narrow_tiles()) {
+      // 64 x 64 tiles: twice the workgroups, 70 KB of LDS each => two co-resident workgroups per CU with
+      // independent barriers (two waves per SIMD) instead of one
+      a.ntiles = (int)ceil_div(a.N, 64);
+      const dim3 g64(a.mtiles * a.ntiles);
+      if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
+    } else if (deep) {
       if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 64>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 64>), grid, dim3(kGemmThreads), 0, stream, a);
     } else {
