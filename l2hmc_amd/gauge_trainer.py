@@ -182,6 +182,87 @@ class GaugeTrainer:
         self.apply_gradients()
         return out
 
+    def update_beta(self, step, beta_init=2., beta_final=4., train_steps=10000):
+        """gauge_model.py:1039-1046: linear annealing of 1/beta."""
+        temp = (1. / beta_init - 1. / beta_final) * (1. - step / float(train_steps)) + 1. / beta_final
+        return 1. / temp
+
+    def train(self, train_steps, samples_init=None, beta_init=2., beta_final=4., initial_step=0, print_steps=0,
+              log=print):
+        """gauge_model.py:1119-1300 without the file / TensorBoard side effects: per step anneal beta, run the
+        train op on the current samples, wrap the new samples to [0, 2 pi) (device side), record loss, accept
+        probability, step size, learning rate and the observables of the step's INPUT samples (:256-266).
+        Returns {'loss', 'accept_prob', 'eps', 'lr', 'beta', 'actions', 'plaqs', 'charges', 'charge_diff',
+        'samples'} with per-step NumPy histories; the chain state never leaves the device inside the loop."""
+        import numpy as np
+        dyn = self.dynamics
+        T, X = dyn.lattice.time_size, dyn.lattice.space_size
+        if samples_init is None:
+            samples_init = np.asarray(dyn.lattice.samples, dtype=np.float32).reshape(dyn.batch_size, dyn.x_dim)
+        x = dyn._x(samples_init).clone()
+        hist = {k: [] for k in ("loss", "accept_prob", "eps", "lr", "beta", "actions", "plaqs", "charges",
+                                "charge_diff")}
+        for step in range(initial_step, train_steps):
+            beta = self.update_beta(step, beta_init, beta_final, train_steps)
+            lr = self.learning_rate()
+            obs = u1_observables(x, T, X)
+            loss, x_out, px, x_dq = self.train_step(x, beta)
+            _lib.check(_lib.lib().l2hmc_wrap_angle(x_out.data_ptr(), x_out.numel(), x.data_ptr(), _lib.stream_ptr()))
+            for k, v in (("loss", loss), ("accept_prob", px.mean()), ("actions", obs["action"].mean()),
+                         ("plaqs", obs["avg_plaq"].mean()), ("charges", obs["top_charge"]),
+                         ("charge_diff", x_dq.sum() / float(x_dq.numel()))):
+                hist[k].append(v)
+            hist["eps"].append(float(dyn.eps))
+            hist["lr"].append(lr)
+            hist["beta"].append(beta)
+            if print_steps and step % print_steps == 0:
+                log(f"{step:>5g}/{train_steps:<6g} loss {float(loss):^9.4g} acc {float(px.mean()):^9.4g} "
+                    f"eps {float(dyn.eps):^9.4g} beta {beta:^9.4g} plaq {float(obs['avg_plaq'].mean()):^9.4g} "
+                    f"lr {lr:^9.4g}")
+        out = {k: (torch.stack(v).cpu().numpy() if v and isinstance(v[0], torch.Tensor) else np.asarray(v))
+               for k, v in hist.items()}
+        out["samples"] = x
+        return out
+
+    # ---- resumable state (gauge_model.py:519-556 `_current_state` + save_weights; .npz, never a pickle) ----
+    def save_state(self, path, samples=None, beta=None):
+        """Everything a resumed run needs: weights and Adam moments in the flat layout, step size, counters,
+        masks, and optionally the chain state and beta of `_current_state`."""
+        import numpy as np
+        d = {"xnet": self._nets[0].flat_params()[0], "vnet": self._nets[1].flat_params()[0], "adam_m": self._m,
+             "adam_v": self._v, "eps": self._eps_dev, "masks": self.dynamics.mask}
+        out = {k: v.detach().cpu().numpy() for k, v in d.items()}
+        out.update(global_step=np.int64(self.global_step), adam_t=np.int64(getattr(self, "_adam_t", 0)),
+                   lr=np.float64(self.learning_rate()), draws=np.int64(self.dynamics._draws))
+        if samples is not None:
+            out["samples"] = samples.detach().cpu().numpy() if isinstance(samples, torch.Tensor) else np.asarray(samples)
+        if beta is not None:
+            out["beta"] = np.float64(beta)
+        np.savez(path, **out)
+
+    def load_state(self, path):
+        """Inverse of save_state; returns {'samples', 'beta'} when they were stored."""
+        import numpy as np
+        dyn = self.dynamics
+        with np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False) as f:
+            for net, key in zip(self._nets, ("xnet", "vnet")):
+                flat = net.flat_params()[0]
+                if f[key].shape != tuple(flat.shape):
+                    raise ValueError(f"{key}: stored {f[key].shape}, expected {tuple(flat.shape)}")
+                flat.copy_(torch.from_numpy(f[key]))
+                net.pack()
+                net.refresh_packed()
+            self._m.copy_(torch.from_numpy(f["adam_m"]))
+            self._v.copy_(torch.from_numpy(f["adam_v"]))
+            self._eps_dev.copy_(torch.from_numpy(f["eps"]))
+            dyn.eps = self._eps_dev.detach().cpu().reshape(())
+            dyn.set_masks(f["masks"])
+            self.global_step, self._adam_t = int(f["global_step"]), int(f["adam_t"])
+            dyn._draws = int(f["draws"])
+            extra = {k: f[k] for k in ("samples", "beta") if k in f.files}
+        self.sync_weights()
+        return extra
+
     def sync_weights(self):
         """Bring the reference-layout layer tensors (state_dict / save_weights) up to date."""
         for net in self._nets:

@@ -26,3 +26,119 @@ def ESS(A):
     A = np.asarray(A, dtype=np.float64)
     A = A * (A > 0.05)
     return 1. / (1. + 2 * np.sum(A[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# Integrated autocorrelation time (l2hmc/utils/autocorr.py:23-199), batched over chains.
+# The reference loops over walkers and parameters in Python with one FFT each; here every series
+# of a [steps, chains, dims] history goes through ONE batched FFT (NumPy on the host, or torch.fft
+# on the device the history already lives on when a tensor is passed).
+# ---------------------------------------------------------------------------------------------
+class AutocorrError(Exception):
+    """Chain too short for a reliable estimate (autocorr.py:181-196); carries the estimate."""
+
+    def __init__(self, tau, *args):
+        self.tau = tau
+        super().__init__(*args)
+
+
+def next_pow_two(n):
+    """Smallest power of two >= n (autocorr.py:82-87)."""
+    return 1 << max(0, int(n) - 1).bit_length()
+
+
+def _acf_batched(x, nfft):
+    """Unnormalised circular-padded autocorrelation along axis 0 of x [n, ...] (mean removed)."""
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            x = x.to(torch.float64)
+            x = x - x.mean(dim=0, keepdim=True)
+            f = torch.fft.rfft(x, n=nfft, dim=0)
+            return torch.fft.irfft(f * f.conj(), n=nfft, dim=0)[: x.shape[0]].cpu().numpy()
+    except ImportError:      # pragma: no cover
+        pass
+    x = np.asarray(x, dtype=np.float64)
+    x = x - x.mean(axis=0, keepdims=True)
+    f = np.fft.rfft(x, n=nfft, axis=0)
+    return np.fft.irfft(f * np.conj(f), n=nfft, axis=0)[: x.shape[0]]
+
+
+def autocorr_func_1d(x):
+    """Normalised autocorrelation function of series along axis 0 (autocorr.py:107-126; a 1-D input
+    gives the reference's result, more axes are treated as independent series)."""
+    if not hasattr(x, "shape") or len(x.shape) == 0:
+        x = np.atleast_1d(x)
+    acf = _acf_batched(x, 2 * next_pow_two(x.shape[0]))
+    return acf / acf[0]
+
+
+def autocorr_fast(X, kappa=500):
+    """autocorr.py:23-34: FFT autocorrelation with the unbiased 1/(N-k) weights, truncated at kappa."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    acf = _acf_batched(X, 2 * N)
+    acf = acf / (N - np.arange(N)).reshape((-1,) + (1,) * (acf.ndim - 1))
+    return (acf / acf[0])[:kappa]
+
+
+def autocorr(X):
+    """autocorr.py:36-40: np.correlate(X, X, 'full') normalised by its maximum, non-negative lags
+    (no mean removal, as the reference)."""
+    X = np.asarray(X, dtype=np.float64)
+    n = X.shape[0]
+    f = np.fft.rfft(X, n=2 * n)
+    full = np.fft.irfft(f * np.conj(f), n=2 * n)[:n]
+    return full / full[0]                # the maximum of an autocorrelation sits at lag 0
+
+
+def calc_iat(X, kappa=500):
+    """autocorr.py:70-76 -> (tau, curve) with tau = 1 + 2 sum(curve) (the lag-0 term included, as written)."""
+    curve = autocorr_fast(X, kappa)
+    return 1 + 2 * np.sum(curve, axis=0), curve
+
+
+def auto_window(taus, c):
+    """autocorr.py:128-132: first lag m with m >= c * tau(m)."""
+    m = np.arange(len(taus)) < c * taus
+    return int(np.argmin(m)) if np.any(m) else len(taus) - 1
+
+
+def integrated_time(x, c=5, tol=50, quiet=False):
+    """autocorr.py:134-199 (Sokal's automatic windowing, averaged over walkers): x [steps] |
+    [steps, walkers] | [steps, walkers, dims] -> (tau per dim, flag)."""
+    if not hasattr(x, "shape"):
+        x = np.atleast_1d(x)
+    if len(x.shape) == 1:
+        x = x[:, None, None]
+    if len(x.shape) == 2:
+        x = x[:, :, None]
+    if len(x.shape) != 3:
+        raise ValueError("invalid dimensions")
+    n_t, _, n_d = x.shape
+    f = autocorr_func_1d(x).mean(axis=1)                    # [steps, dims]
+    taus = 2.0 * np.cumsum(f, axis=0) - 1.0
+    windows = np.array([auto_window(taus[:, d], c) for d in range(n_d)])
+    tau_est = taus[windows, np.arange(n_d)]
+    flag = None
+    if np.any(tol * tau_est > n_t):
+        msg = (f"The chain is shorter than {tol} times the integrated autocorrelation time for "
+               f"{int(np.sum(tol * tau_est > n_t))} parameter(s). N/{tol} = {n_t / tol:.0f}; tau: {tau_est}")
+        if not quiet:
+            raise AutocorrError(tau_est, msg)
+        flag = 1
+    return tau_est, flag
+
+
+def autocorr_gw2010(y, c=5.0):
+    """autocorr.py:89-94 (Goodman & Weare 2010): y [walkers, steps]."""
+    f = autocorr_func_1d(np.mean(np.asarray(y, dtype=np.float64), axis=0))
+    taus = 2. * np.cumsum(f) - 1.0
+    return taus[auto_window(taus, c)]
+
+
+def autocorr_new(y, c=5.0):
+    """autocorr.py:96-103: y [walkers, steps], walker-averaged autocorrelation function."""
+    f = autocorr_func_1d(np.asarray(y, dtype=np.float64).T).mean(axis=1)
+    taus = 2. * np.cumsum(f) - 1.
+    return taus[auto_window(taus, c)]

@@ -226,3 +226,35 @@ def test_data_parallel_gradients_equal_full_batch(tmp_path):
     scale = np.abs(full).max()
     assert np.abs(got - full).max() <= 2e-5 * scale      # summation order differs between 1 and 2 shards
     assert lr == pytest.approx(2 * tr.learning_rate())    # gauge_model.py:942: lr * hvd.size()
+
+
+def test_save_and_resume_reproduces_the_next_step(tmp_path):
+    """gauge_model.py:519-556: a run restored from its saved state continues identically (weights, Adam moments,
+    step size, counters, RNG draw counter)."""
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, 8, "mild")
+    for _ in range(3):
+        tr.train_step(x, 2.0)                     # library-drawn z / momenta: exercises the draw counter
+    path = str(tmp_path / "state.npz")
+    tr.save_state(path, samples=x, beta=2.0)
+    a = tr.train_step(x, 2.0)
+    wa = [n.flat_params()[0].clone() for n in tr._nets]
+    tr2, *_ = _setup(4, 2, 0.2, 8, "init", seed=99)       # different weights, masks of the same seed
+    extra = tr2.load_state(path)
+    assert float(extra["beta"]) == 2.0 and extra["samples"].shape == x.shape
+    b = tr2.train_step(x, 2.0)
+    assert float(a[0]) == float(b[0])
+    for p, q in zip(wa, [n.flat_params()[0] for n in tr2._nets]):
+        assert torch.equal(p, q)
+    assert float(tr.dynamics.eps) == float(tr2.dynamics.eps) and tr.global_step == tr2.global_step
+
+
+def test_train_loop_anneals_beta_and_keeps_samples_wrapped():
+    tr, tm, x, z, dx, dz = _setup(4, 2, 0.1, 16, "init")
+    tr.lr_init = 1e-4
+    out = tr.train(5, samples_init=x, beta_init=2., beta_final=3.)
+    assert out["loss"].shape == (5,) and out["charges"].shape == (5, 16) and np.isfinite(out["loss"]).all()
+    want_beta = [1. / ((1. / 2 - 1. / 3) * (1 - s / 5.) + 1. / 3) for s in range(5)]       # gauge_model.py:1039-1046
+    np.testing.assert_allclose(out["beta"], want_beta, rtol=1e-12)
+    xs = out["samples"].cpu().numpy()
+    assert (xs >= 0).all() and (xs < 2 * np.pi + 1e-6).all()
+    assert tr.global_step == 5 and len(set(out["eps"])) > 1                                  # eps is being trained

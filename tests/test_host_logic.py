@@ -182,3 +182,55 @@ def test_golden_small_targets(name, target):
     np.testing.assert_allclose(pf, g["pf"], rtol=1e-9, atol=1e-12)
     Lx, Lv, px, outs, _ = ogen.propose(g["x"], orc, g["v0f"], g["v0b"], g["dir_bits"], g["u"], do_mh_step=True)
     np.testing.assert_allclose(outs[0], g["x_accept"], rtol=1e-9, atol=1e-9)
+
+
+# ---- chain statistics: FFT formulations vs direct lag sums, and a known answer -------
+def _ar1(n, walkers, rho, seed=5):
+    rng = np.random.default_rng(seed)
+    x = np.zeros((n, walkers))
+    e = rng.standard_normal((n, walkers))
+    for t in range(1, n):
+        x[t] = rho * x[t - 1] + e[t]
+    return x
+
+
+def test_autocorr_functions_match_direct_lag_sums():
+    from l2hmc_amd import stats
+    from oracle import stats as ostats
+    x = _ar1(257, 3, 0.6)
+    np.testing.assert_allclose(stats.autocorr_func_1d(x[:, 0]), ostats.acf_direct(x[:, 0]), atol=1e-12)
+    np.testing.assert_allclose(stats.autocorr_func_1d(x)[:, 2], ostats.acf_direct(x[:, 2]), atol=1e-12)
+    np.testing.assert_allclose(stats.autocorr_fast(x[:, 1], kappa=100),
+                               ostats.acf_direct(x[:, 1], unbiased=True)[:100], atol=1e-12)
+    y = x[:, 0] + 2.0                   # autocorr() does not remove the mean
+    want = np.correlate(y, y, mode='full')
+    want = (want / want[want.argmax()])[want.size // 2:]
+    np.testing.assert_allclose(stats.autocorr(y), want, atol=1e-12)
+    tau, curve = stats.calc_iat(x[:, 0], kappa=50)
+    assert tau == pytest.approx(1 + 2 * curve.sum())
+    assert stats.next_pow_two(1) == 1 and stats.next_pow_two(257) == 512 and stats.next_pow_two(512) == 512
+    # torch input (device-resident histories) goes through torch.fft with the same result
+    import torch
+    np.testing.assert_allclose(stats.autocorr_func_1d(torch.as_tensor(x)), stats.autocorr_func_1d(x), atol=1e-10)
+
+
+def test_integrated_time_known_answer_and_errors():
+    from l2hmc_amd import stats
+    from oracle import stats as ostats
+    rho = 0.5
+    x = _ar1(20000, 8, rho)
+    tau, flag = stats.integrated_time(x)
+    assert flag is None
+    assert tau[0] == pytest.approx((1 + rho) / (1 - rho), rel=0.1)          # AR(1): tau_int = (1+rho)/(1-rho)
+    assert tau[0] == pytest.approx(ostats.integrated_time_direct(x[:2000], 5), rel=0.25)
+    short = _ar1(300, 4, 0.5)
+    assert stats.integrated_time(short, quiet=True)[0][0] == pytest.approx(ostats.integrated_time_direct(short), rel=1e-9)
+    with pytest.raises(stats.AutocorrError) as e:
+        stats.integrated_time(_ar1(60, 2, 0.9))
+    assert e.value.tau.shape == (1,)
+    assert stats.integrated_time(_ar1(60, 2, 0.9), quiet=True)[1] == 1
+    with pytest.raises(ValueError):
+        stats.integrated_time(np.zeros((4, 2, 2, 2)))
+    w = _ar1(4000, 6, 0.5).T
+    assert stats.autocorr_new(w) == pytest.approx(3.0, rel=0.2)
+    assert stats.autocorr_gw2010(w) > 0
