@@ -237,7 +237,7 @@ int l2hmc_gauge_loss_terms(const float* x, const float* x_prop, const float* px,
 /* ------------------------------------------------------------------------
  * Training: gradients of the loss with respect to the network weights and the step size, and the
  * optimiser step -- tf.gradients(loss, dynamics.variables) + AdamOptimizer.apply_gradients of
- * gauge_model.py:799-830, :942-969.  GenericNet plans only (flags without L2HMC_PLAN_CONV3D, hmc = 0).
+ * gauge_model.py:799-830, :942-969.  GenericNet and ConvNet3D plans (hmc = 0).
  *
  * Chains are integrated in the direction their coin selects (rows = x chains then z chains for the
  * loss of gauge_model.py:728-797; the masked-out direction carries exactly zero gradient in the
@@ -260,6 +260,13 @@ typedef struct l2hmc_dense_grads {
   float* coeff_q;  /* [D]     */
 } l2hmc_dense_grads;
 
+/* Gradients of a ConvNet3D front-end, in the Keras layout of the weights (struct l2hmc_conv3d_front);
+ * the dd = 1 slice of the second kernel only ever multiplies padding, so its gradient is exactly 0. */
+typedef struct l2hmc_conv3d_grads {
+  float* w1_a; float* b1_a; float* w2_a; float* b2_a;   /* first input  */
+  float* w1_b; float* b1_b; float* w2_b; float* b2_b;   /* second input */
+} l2hmc_conv3d_grads;
+
 size_t l2hmc_gauge_train_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);
 /* Same outputs as l2hmc_gauge_trajectory (dir: per-row 0 forward / 1 backward, NULL = all forward);
  * `ws` must stay untouched until the matching l2hmc_gauge_train_backward has run. */
@@ -267,10 +274,13 @@ int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float beta, const fl
                               const int32_t* dir, int64_t rows, float* x_out, float* v_out, float* sumlogdet,
                               float* p_accept, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
 /* dx, dv: [rows][D] = d loss / d (x_N, v_N) on entry, overwritten (d loss / d (x_0, v_0) on exit);
- * dlogdet: [rows] = d loss / d sumlogdet.  gx, gv, deps (1 float) are overwritten with the gradients. */
+ * dlogdet: [rows] = d loss / d sumlogdet.  gx, gv, deps (1 float) are overwritten with the gradients.
+ * gxf, gvf: for L2HMC_PLAN_CONV3D plans, where the gradients of the Conv3D kernels / biases go; NULL for
+ * GenericNet plans. */
 int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
                                float* dx, float* dv, const float* dlogdet, const l2hmc_dense_grads* gx,
-                               const l2hmc_dense_grads* gv, float* deps, void* ws, size_t ws_bytes,
+                               const l2hmc_dense_grads* gv, const l2hmc_conv3d_grads* gxf,
+                               const l2hmc_conv3d_grads* gvf, float* deps, void* ws, size_t ws_bytes,
                                l2hmc_stream_t stream);
 /* Loss (gauge_model.py:728-797) and its gradient with respect to the proposed states of the 2B stacked
  * chains (rows [0,B): started at x; rows [B,2B): started at z), through the accept probabilities

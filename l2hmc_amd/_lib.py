@@ -30,6 +30,10 @@ class DenseGrads(C.Structure):
     _fields_ = [(n, c_float_p) for n in ("w1_t", "wt", "b1", "wh_t", "bh", "whd_t", "bhd", "coeff_s", "coeff_q")]
 
 
+class Conv3DGrads(C.Structure):
+    _fields_ = [(n, c_float_p) for n in ("w1_a", "b1_a", "w2_a", "b2_a", "w1_b", "b1_b", "w2_b", "b2_b")]
+
+
 class Conv3DFront(C.Structure):
     _fields_ = [("F", C.c_int32), ("reserved", C.c_int32),
                 ("w1_a", c_float_p), ("b1_a", c_float_p), ("w2_a", c_float_p), ("b2_a", c_float_p),
@@ -88,7 +92,8 @@ _PROTOS = {
     "l2hmc_gauge_train_forward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ,
                                             _P]),
     "l2hmc_gauge_train_backward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _P, _P, _P,
-                                             C.POINTER(DenseGrads), C.POINTER(DenseGrads), _P, _P, _SZ, _P]),
+                                             C.POINTER(DenseGrads), C.POINTER(DenseGrads),
+                                             C.POINTER(Conv3DGrads), C.POINTER(Conv3DGrads), _P, _P, _SZ, _P]),
     "l2hmc_gauge_loss_backward": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _P, _P,
                                             _P, _P, _P]),
     "l2hmc_grad_sumsq": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P]),

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   const bool masked = which == 1 && p.cmask_f != nullptr;
   for (int i = tid; i < nrow * D; i += kConvThreads) {
     const int c = i / D, e = i - c * D;
-    float v = in[(row0 + c) * D + e];
+    float v = in[(row0 + c) * p.ldi + e];
     if (masked) {
       const int d = p.dir ? p.dir[row0 + c] : 0;
       v *= (d ? p.cmask_b : p.cmask_f)[e];
@@ -147,6 +147,7 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                 "conv3d front-end: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
   a.cpw = per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
+  if (a.ldi == 0) a.ldi = 2 * a.T * a.X;
   const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
                                       (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
@@ -160,6 +161,268 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
   hipLaunchKernelGGL(conv3d_front_kernel, grid, dim3(kConvThreads), lds, stream, a);
   L2HMC_CHECK_LAUNCH("conv3d_front");
+  return L2HMC_OK;
+}
+
+// =====================================================================================
+// Backward of the front-end for the training path (train.hip): given d loss / d features of one
+// network call, the gradient with respect to the raw inputs and to the filters / biases.
+// The forward is recomputed from the taped inputs (a chain is a few hundred floats; keeping the
+// pooling winners of every call in HBM would cost more than recomputing them in LDS).
+// Max-pooling routes each pooled cell's gradient to its single winner, so everything downstream is
+// sparse: the kernel records the winner of every pooled cell (arg1: one of 2x2x2 conv1 outputs,
+// arg2: one of 2x2 conv2 outputs; 255 = the relu killed it) and every later phase is a GATHER in
+// which a thread owns its output element -- no atomics, fixed summation order.
+// Filter gradients are accumulated (+=) into this workgroup's own slot of `part`
+// ([workgroup][input][18F | F | 16F^2 (Keras layout, dd = 1 rows stay 0) | 2F]); the same workgroup
+// sees the same chains in every call, and the slots are summed in order afterwards.
+// =====================================================================================
+__global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int which = blockIdx.y;
+  const int T = p.T, X = p.X, F = p.F, F2 = 2 * p.F;
+  const int D = 2 * T * X;
+  const int TP = T + 2, XP = X + 2;
+  const int T2 = T / 2, X2 = X / 2, T2P = T2 + 1, X2P = X2 + 1;
+  const int T4 = T / 4, X4 = X / 4;
+  const int cpw = p.cpw;
+  float* w1 = lds;                                 // [3][3][2][F]
+  float* b1 = w1 + 18 * F;
+  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice)
+  float* b2 = w2 + 4 * F * F2;
+  float* xin = b2 + F2;                            // [cpw][TP][XP][2]
+  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][F]
+  float* dpre1 = p1 + cpw * T2P * X2P * F;         // [cpw][T2][X2][F]   gradient at the winning conv1 output
+  float* d2 = dpre1 + cpw * T2 * X2 * F;           // [cpw][T4][X4][2F]  gradient at the winning conv2 output
+  unsigned char* arg1 = reinterpret_cast<unsigned char*>(d2 + cpw * T4 * X4 * F2);   // [cpw][T2][X2][F]
+  unsigned char* arg2 = arg1 + cpw * T2 * X2 * F;                                    // [cpw][T4][X4][2F]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * cpw;
+  const int nrow = (int)min((int64_t)cpw, p.rows - row0);
+
+  const float* gw1 = p.w1[which];
+  const float* gw2 = p.w2[which];
+  for (int i = tid; i < 18 * F; i += kConvThreads) w1[i] = gw1[i];
+  for (int i = tid; i < F; i += kConvThreads) b1[i] = p.b1[which][i];
+  for (int i = tid; i < 4 * F * F2; i += kConvThreads) {
+    const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
+    w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
+  }
+  for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
+  for (int i = tid; i < cpw * TP * XP * 2; i += kConvThreads) xin[i] = 0.f;
+  for (int i = tid; i < cpw * T2P * X2P * F; i += kConvThreads) p1[i] = 0.f;
+  __syncthreads();
+  const float* in = p.in + which * D;
+  for (int i = tid; i < nrow * D; i += kConvThreads) {
+    const int c = i / D, e = i - c * D;
+    const int site = e >> 1, mu = e & 1;
+    const int ii = site / X, jj = site - ii * X;
+    xin[((c * TP + ii + 1) * XP + jj + 1) * 2 + mu] = in[(row0 + c) * p.ldi + e];
+  }
+  __syncthreads();
+
+  // ---- phase 1: conv1 + pool1, remember the winner of each pooled cell
+  const int n1 = nrow * T2 * X2 * F;
+  for (int idx = tid; idx < n1; idx += kConvThreads) {
+    const int f = idx % F;
+    int r = idx / F;
+    const int J = r % X2;
+    r /= X2;
+    const int I = r % T2, c = r / T2;
+    const float bias = b1[f];
+    float m = -INFINITY;
+    int code = 255;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int i = 2 * I + a, j = 2 * J + bb;
+        float v0 = bias, v1 = bias;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+#pragma unroll
+          for (int dj = 0; dj < 3; ++dj) {
+            const float* px = xin + ((c * TP + i + di) * XP + j + dj) * 2;
+            const float x0 = px[0], x1 = px[1];
+            const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
+            v0 += x0 * k0 + x1 * k1;
+            v1 += x1 * k0;
+          }
+        }
+        if (v0 > m) { m = v0; code = (a * 2 + bb) * 2; }
+        if (v1 > m) { m = v1; code = (a * 2 + bb) * 2 + 1; }
+      }
+    }
+    p1[((c * T2P + I) * X2P + J) * F + f] = fmaxf(m, 0.f);
+    arg1[idx] = (unsigned char)(m > 0.f ? code : 255);
+  }
+  __syncthreads();
+
+  // ---- phase 2: conv2 + pool2 winners; gradient of the surviving features
+  const int n2 = nrow * T4 * X4 * F2;
+  for (int idx = tid; idx < n2; idx += kConvThreads) {
+    const int g = idx % F2;
+    int r = idx / F2;
+    const int J2 = r % X4;
+    r /= X4;
+    const int I2 = r % T4, c = r / T4;
+    const float bias = b2[g];
+    float acc[2][2] = {{bias, bias}, {bias, bias}};
+    const float* pbase = p1 + ((c * T2P + 2 * I2) * X2P + 2 * J2) * F;
+    for (int ch = 0; ch < F; ++ch) {
+#pragma unroll
+      for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          const float kw = w2[((di * 2 + dj) * F + ch) * F2 + g];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) acc[a][bb] += pbase[((a + di) * X2P + bb + dj) * F + ch] * kw;
+        }
+    }
+    float m = -INFINITY;
+    int code = 255;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+        if (acc[a][bb] > m) { m = acc[a][bb]; code = a * 2 + bb; }
+    const bool alive = m > 0.f;
+    arg2[idx] = (unsigned char)(alive ? code : 255);
+    d2[idx] = alive ? p.dfeat[(row0 + c) * p.ldf + which * (T4 * X4 * F2) + (I2 * X4 + J2) * F2 + g] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 3: gradient of the pooled conv1 map, gated by its own relu / winner
+  for (int idx = tid; idx < n1; idx += kConvThreads) {
+    const int ch = idx % F;
+    int r = idx / F;
+    const int J = r % X2;
+    r /= X2;
+    const int I = r % T2, c = r / T2;
+    float dp = 0.f;
+    if (arg1[idx] != 255) {
+#pragma unroll
+      for (int di = 0; di < 2; ++di) {
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          const int i2 = I - di, j2 = J - dj;       // conv2 output whose tap (di, dj) reads p1[I, J]
+          if (i2 < 0 || j2 < 0) continue;
+          const int cell = ((c * T4 + (i2 >> 1)) * X4 + (j2 >> 1)) * F2;
+          const int want = (i2 & 1) * 2 + (j2 & 1);
+          const float* kw = w2 + ((di * 2 + dj) * F + ch) * F2;
+          for (int g = 0; g < F2; ++g)
+            if (arg2[cell + g] == want) dp += d2[cell + g] * kw[g];
+        }
+      }
+    }
+    dpre1[idx] = dp;
+  }
+  __syncthreads();
+
+  // ---- phase 4: gradient of the raw input (zero padding: no periodic wrap, as the forward)
+  for (int i = tid; i < nrow * D; i += kConvThreads) {
+    const int c = i / D, e = i - c * D;
+    const int site = e >> 1, mu = e & 1;
+    const int ip = site / X, jp = site - ip * X;
+    const int Ilo = max(ip - 1, 0) >> 1, Ihi = min(ip + 1, T - 1) >> 1;
+    const int Jlo = max(jp - 1, 0) >> 1, Jhi = min(jp + 1, X - 1) >> 1;
+    float gsum = 0.f;
+    for (int I = Ilo; I <= Ihi; ++I)
+      for (int J = Jlo; J <= Jhi; ++J) {
+        const int cell = ((c * T2 + I) * X2 + J) * F;
+        for (int f = 0; f < F; ++f) {
+          const int code = arg1[cell + f];
+          if (code == 255) continue;
+          const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
+          const int di = ip - (2 * I + a) + 1, dj = jp - (2 * J + bb) + 1;
+          if (di < 0 || di > 2 || dj < 0 || dj > 2) continue;
+          // output depth 0 reads (mu = 0, dd = 0) and (mu = 1, dd = 1); depth 1 reads (mu = 1, dd = 0) and padding
+          int dd;
+          if (depth == 0) dd = mu;
+          else if (mu == 1) dd = 0;
+          else continue;
+          gsum += dpre1[cell + f] * w1[((di * 3 + dj) * 2 + dd) * F + f];
+        }
+      }
+    p.din[(row0 + c) * p.ldd + which * D + e] = gsum;
+  }
+
+  // ---- phase 5: filter / bias gradients, one owner thread per entry
+  const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
+  float* part = p.part + ((size_t)blockIdx.x * 2 + which) * psize;
+  for (int ent = tid; ent < 18 * F; ent += kConvThreads) {
+    const int f = ent % F, dd = (ent / F) & 1, tap = ent / (2 * F);
+    const int di = tap / 3, dj = tap - di * 3;
+    float s = 0.f;
+    for (int c = 0; c < nrow; ++c)
+      for (int I = 0; I < T2; ++I)
+        for (int J = 0; J < X2; ++J) {
+          const int cell = ((c * T2 + I) * X2 + J) * F + f;
+          const int code = arg1[cell];
+          if (code == 255) continue;
+          const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
+          const float* px = xin + ((c * TP + 2 * I + a + di) * XP + 2 * J + bb + dj) * 2;
+          const float xv = depth == 0 ? px[dd] : (dd == 0 ? px[1] : 0.f);
+          s += dpre1[cell] * xv;
+        }
+    part[ent] += s;
+  }
+  for (int f = tid; f < F; f += kConvThreads) {
+    float s = 0.f;
+    for (int cell = 0; cell < nrow * T2 * X2; ++cell) s += dpre1[cell * F + f];
+    part[18 * F + f] += s;
+  }
+  float* pw2 = part + 18 * F + F;
+  for (int ent = tid; ent < 4 * F * F2; ent += kConvThreads) {
+    const int g = ent % F2, ch = (ent / F2) % F, tap = ent / (F2 * F);
+    const int di = tap >> 1, dj = tap & 1;
+    float s = 0.f;
+    for (int c = 0; c < nrow; ++c)
+      for (int I2 = 0; I2 < T4; ++I2)
+        for (int J2 = 0; J2 < X4; ++J2) {
+          const int cell = ((c * T4 + I2) * X4 + J2) * F2 + g;
+          const int code = arg2[cell];
+          if (code == 255) continue;
+          const int i2 = 2 * I2 + (code >> 1), j2 = 2 * J2 + (code & 1);
+          s += d2[cell] * p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
+        }
+    pw2[((size_t)(tap * 2 + 0) * F + ch) * F2 + g] += s;
+  }
+  float* pb2 = pw2 + (size_t)16 * F * F;
+  for (int g = tid; g < F2; g += kConvThreads) {
+    float s = 0.f;
+    for (int cell = 0; cell < nrow * T4 * X4; ++cell) s += d2[cell * F2 + g];
+    pb2[g] += s;
+  }
+}
+
+size_t conv3d_bwd_part_floats(int F) { return (size_t)18 * F + F + (size_t)16 * F * F + 2 * F; }
+int conv3d_cpw(int T, int X, int F) {
+  const int per_chain = (T / 2) * (X / 2) * F;
+  return per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
+}
+
+int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
+  L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
+                "conv3d front-end backward: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
+  a.cpw = conv3d_cpw(a.T, a.X, a.F);
+  const size_t cells1 = (size_t)a.cpw * (a.T / 2) * (a.X / 2) * a.F, cells2 = (size_t)a.cpw * (a.T / 4) * (a.X / 4) * 2 * a.F;
+  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
+                                      (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
+                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F + cells1 + cells2) +
+                     align_up(cells1 + cells2, 16);
+  L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
+  hipLaunchKernelGGL(conv3d_front_bwd_kernel, grid, dim3(kConvThreads), lds, stream, a);
+  L2HMC_CHECK_LAUNCH("conv3d_front_bwd");
   return L2HMC_OK;
 }
 

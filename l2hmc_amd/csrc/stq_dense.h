@@ -83,7 +83,24 @@ struct ConvFrontArgs {
   float* out[2]; int ldo;                // [rows][nflat] flattened features
   int64_t rows;
   int cpw;                               // chains per workgroup (set by the launcher)
+  int ldi;                               // row stride of `in` (0 = 2*T*X)
 };
+
+// backward of the front-end (training path); input `which` lives at column offset which*D of `in` / `din`
+// and which*nflat of `dfeat`
+struct ConvBwdArgs {
+  int T, X, F;
+  const float* in; int ldi;              // taped raw inputs [rows][>= 2D]
+  const float* dfeat; int ldf;           // d loss / d features [rows][>= 2*nflat]
+  const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
+  float* din; int ldd;                   // out: d loss / d raw inputs [rows][>= 2D]
+  float* part;                           // [workgroups][2][conv3d_bwd_part_floats(F)], +=
+  int64_t rows;
+  int cpw;
+};
+size_t conv3d_bwd_part_floats(int F);
+int conv3d_cpw(int T, int X, int F);
+int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream);
 int conv3d_nflat(int T, int X, int F);
 int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream);
 

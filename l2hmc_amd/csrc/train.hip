@@ -690,10 +690,12 @@ struct NetTape {
   float *in, *h1, *h2, *stq, *st, *d1, *d2, *dout;   // [calls][rows][.]
   float *dcs_part, *dcq_part;                         // [nblk][D]
   float *w1_n, *wh_n, *whd_n;                         // weights transposed for the backward-data products
+  float *feat;                                        // ConvNet3D: [calls][rows][Ka+Kb] front-end features
+  float *conv_part;                                   // ConvNet3D: [workgroups][2][filter-gradient slot]
 };
 struct TrainWs {
   NetTape x, v;
-  float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *part, *eps_part;
+  float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *dfeat, *part, *eps_part;
   size_t bytes;
 };
 
@@ -718,10 +720,15 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     return q;
   };
   const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
+  const l2hmc_conv3d_front* fronts[2] = {&p->xfront, &p->vfront};
+  const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   NetTape* tapes[2] = {&w.x, &w.v};
   size_t part_max = 0;
+  int kin_max = 2 * D;
   for (int k = 0; k < 2; ++k) {
     const int H = nets[k]->H;
+    const int Kin = nets[k]->Ka + nets[k]->Kb;         // first-layer fan-in: 2D (generic) or 2*nflat (ConvNet3D)
+    kin_max = hmax(kin_max, Kin);
     NetTape& t = *tapes[k];
     const size_t cr = (size_t)C * rows;
     t.in = take(cr * 2 * D);
@@ -734,7 +741,11 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     t.dout = take(cr * 3 * D);
     t.dcs_part = take((size_t)upd_blocks(rows) * D);
     t.dcq_part = take((size_t)upd_blocks(rows) * D);
-    t.w1_n = take((size_t)2 * D * H);
+    t.feat = conv ? take(cr * Kin) : nullptr;
+    t.conv_part = conv ? take((size_t)ceil_div(rows, conv3d_cpw(p->T, p->X, fronts[k]->F)) * 2 *
+                              conv3d_bwd_part_floats(fronts[k]->F))
+                       : nullptr;
+    t.w1_n = take((size_t)Kin * H);
     t.wh_n = take((size_t)H * H);
     t.whd_n = take((size_t)3 * D * H);
     // split-k partials of the three weight-gradient products and the column sums
@@ -743,7 +754,8 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
       const int mt = (int)ceil_div(M, 128), nt = (int)ceil_div(N, 128);
       return (size_t)tn_splits(mt, nt, R) * M * N;
     };
-    part_max = smax(part_max, smax(need(H, 2 * D), smax(need(H, H), need(3 * D, H))));
+    part_max = smax(part_max, smax(need(H, Kin), smax(need(H, H), need(3 * D, H))));
+    if (conv) part_max = smax(part_max, 2 * conv3d_bwd_part_floats(fronts[k]->F));
     part_max = smax(part_max, (size_t)(kColsumMaxS + 1) * 3 * hmax(H, 3 * D));
   }
   w.mask_inv = take((size_t)p->num_steps * D);
@@ -752,6 +764,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   w.g = take((size_t)rows * D);
   w.dg = take((size_t)rows * D);
   w.din = take((size_t)rows * 2 * D);
+  w.dfeat = conv ? take((size_t)rows * kin_max) : nullptr;
   w.part = take(part_max);
   w.eps_part = take(upd_blocks(rows));
   w.bytes = off;
@@ -762,14 +775,21 @@ static int check_train_plan(const l2hmc_gauge_plan* p) {
   L2HMC_REQUIRE(p != nullptr, "train: NULL plan");
   L2HMC_REQUIRE(p->T > 0 && p->X > 0 && p->num_steps > 0 && p->masks != nullptr, "train: bad plan");
   L2HMC_REQUIRE(!p->hmc, "train: hmc plans have no trainable networks");
-  L2HMC_REQUIRE(!(p->flags & L2HMC_PLAN_CONV3D), "train: ConvNet3D plans are not supported yet (generic nets only)");
+  const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   const int D = 2 * p->T * p->X;
   const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
+  const l2hmc_conv3d_front* fronts[2] = {&p->xfront, &p->vfront};
   for (int k = 0; k < 2; ++k) {
     const l2hmc_dense_net* n = nets[k];
-    L2HMC_REQUIRE(dense_net_supported(n) && n->D == D && n->Ka == D && n->Kb == D,
-                  "train: network widths (D=%d Ka=%d Kb=%d H=%d) must be multiples of 32 with Ka = Kb = D = %d",
-                  n->D, n->Ka, n->Kb, n->H, D);
+    const int kin = conv ? conv3d_nflat(p->T, p->X, fronts[k]->F) : D;
+    L2HMC_REQUIRE(dense_net_supported(n) && n->D == D && n->Ka == kin && n->Kb == kin,
+                  "train: network widths (D=%d Ka=%d Kb=%d H=%d) must be multiples of 32 with Ka = Kb = %d",
+                  n->D, n->Ka, n->Kb, n->H, kin);
+    if (conv) {
+      const l2hmc_conv3d_front* f = fronts[k];
+      L2HMC_REQUIRE(f->F > 0 && f->w1_a && f->b1_a && f->w2_a && f->b2_a && f->w1_b && f->b1_b && f->w2_b && f->b2_b,
+                    "train: NULL conv front-end pointer");
+    }
     L2HMC_REQUIRE(n->w1_t && n->wt && n->b1 && n->wh_t && n->bh && n->whd_t && n->bhd && n->coeff_s && n->coeff_q,
                   "train: NULL weight pointer");
   }
@@ -797,10 +817,26 @@ static int taped_call(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, con
   hipLaunchKernelGGL(tape_in_kernel, dim3(rgrid), dim3(256), 0, s, a, b, cm_f, cm_b, dir, state, rows, D, in,
                      t.st + cr * D);
   L2HMC_CHECK_LAUNCH("tape_in");
+  const int Kin = net->Ka + net->Kb;
+  const float* first_in = in;
+  if (p->flags & L2HMC_PLAN_CONV3D) {
+    // conv_net.py:251-262 on the taped (already masked) inputs; the features are taped for the first layer's
+    // weight gradient
+    const l2hmc_conv3d_front* f = (net == &p->xnet) ? &p->xfront : &p->vfront;
+    float* feat = t.feat + cr * Kin;
+    ConvFrontArgs c{};
+    c.T = p->T; c.X = p->X; c.F = f->F;
+    c.in[0] = in; c.in[1] = in + D; c.ldi = 2 * D; c.dir = nullptr;
+    c.w1[0] = f->w1_a; c.b1[0] = f->b1_a; c.w2[0] = f->w2_a; c.b2[0] = f->b2_a;
+    c.w1[1] = f->w1_b; c.b1[1] = f->b1_b; c.w2[1] = f->w2_b; c.b2[1] = f->b2_b;
+    c.out[0] = feat; c.out[1] = feat + net->Ka; c.ldo = Kin; c.rows = rows;
+    if (int e = launch_conv3d_front(c, s)) return e;
+    first_in = feat;
+  }
   GemmReluArgs l1{};
-  l1.A1 = in; l1.lda1 = 2 * D; l1.K1 = 2 * D;
+  l1.A1 = first_in; l1.lda1 = Kin; l1.K1 = Kin;
   l1.dir = dir;
-  l1.Wt = net->w1_t; l1.K = 2 * D; l1.N = H;
+  l1.Wt = net->w1_t; l1.K = Kin; l1.N = H;
   l1.bias = net->b1; l1.wt0 = net->wt; l1.wt1 = net->wt + H;
   l1.tc_f = tcs[0]; l1.ts_f = tcs[1]; l1.tc_b = tcs[2]; l1.ts_b = tcs[3];
   l1.out = h1; l1.ldo = H; l1.rows = rows;
@@ -823,9 +859,10 @@ static int taped_call(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, con
 }
 
 // backward of one network call: heads' pre-activation gradients (in t.dout) -> t.d2, t.d1, w.din
-static int call_backward_data(const l2hmc_dense_net* net, const NetTape& t, int call, int64_t rows, const TrainWs& w,
-                              hipStream_t s) {
-  const int D = net->D, H = net->H;
+static int call_backward_data(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, const NetTape& t, int call,
+                              int64_t rows, const TrainWs& w, hipStream_t s) {
+  const int D = net->D, H = net->H, Kin = net->Ka + net->Kb;
+  const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   const size_t cr = (size_t)call * rows;
   // d2 = (dout . Whd) gated by h2 > 0:   B operand [H][3D] = transpose of whd_t [3D][H]
   GemmReluArgs g2{};
@@ -847,9 +884,20 @@ static int call_backward_data(const l2hmc_dense_net* net, const NetTape& t, int 
   GemmReluArgs g0{};
   g0.kind = 4;
   g0.A1 = t.d1 + cr * H; g0.lda1 = H; g0.K1 = H; g0.K = H;
-  g0.Wt = t.w1_n; g0.N = 2 * D;
-  g0.out = w.din; g0.ldo = 2 * D; g0.rows = rows;
-  return launch_gemm_relu(g0, s);
+  g0.Wt = t.w1_n; g0.N = Kin;
+  g0.out = conv ? w.dfeat : w.din; g0.ldo = Kin; g0.rows = rows;
+  if (int e = launch_gemm_relu(g0, s)) return e;
+  if (!conv) return L2HMC_OK;
+  // through the conv front-end to the raw inputs (w.din) and the filters (t.conv_part)
+  const l2hmc_conv3d_front* f = (net == &p->xnet) ? &p->xfront : &p->vfront;
+  ConvBwdArgs b{};
+  b.T = p->T; b.X = p->X; b.F = f->F;
+  b.in = t.in + cr * 2 * D; b.ldi = 2 * D;
+  b.dfeat = w.dfeat; b.ldf = Kin;
+  b.w1[0] = f->w1_a; b.b1[0] = f->b1_a; b.w2[0] = f->w2_a; b.b2[0] = f->b2_a;
+  b.w1[1] = f->w1_b; b.b1[1] = f->b1_b; b.w2[1] = f->w2_b; b.b2[1] = f->b2_b;
+  b.din = w.din; b.ldd = 2 * D; b.part = t.conv_part; b.rows = rows;
+  return launch_conv3d_front_bwd(b, s);
 }
 
 static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, float* out, const TrainWs& w,
@@ -965,10 +1013,13 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
 
 extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
                                           float* dx, float* dv, const float* dlogdet,
-                                          const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv, float* deps,
+                                          const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv,
+                                          const l2hmc_conv3d_grads* gxf, const l2hmc_conv3d_grads* gvf, float* deps,
                                           void* ws, size_t ws_bytes, l2hmc_stream_t stream) {
   if (int e = check_train_plan(plan)) return e;
   L2HMC_REQUIRE(rows > 0 && dx && dv && dlogdet && gx && gv && deps && ws, "train_backward: bad arguments");
+  const bool conv = (plan->flags & L2HMC_PLAN_CONV3D) != 0;
+  L2HMC_REQUIRE(!conv || (gxf && gvf), "train_backward: ConvNet3D plans need the front-end gradient structs");
   const TrainWs w = carve_train_ws(plan, rows, ws);
   if (ws_bytes < w.bytes) {
     set_error("train_backward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
@@ -985,6 +1036,18 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     set_error("train_backward: memset failed");
     return L2HMC_ERR_HIP;
   }
+  if (conv) {
+    const l2hmc_conv3d_front* fr[2] = {&plan->xfront, &plan->vfront};
+    const NetTape* tp[2] = {&w.x, &w.v};
+    for (int k = 0; k < 2; ++k) {
+      const size_t n = (size_t)ceil_div(rows, conv3d_cpw(plan->T, plan->X, fr[k]->F)) * 2 *
+                       conv3d_bwd_part_floats(fr[k]->F);
+      if (hipMemsetAsync(tp[k]->conv_part, 0, sizeof(float) * n, s) != hipSuccess) {
+        set_error("train_backward: memset failed");
+        return L2HMC_ERR_HIP;
+      }
+    }
+  }
   {
     // weights as the backward-data products read them (k = output unit contiguous), once per pass
     const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
@@ -996,8 +1059,9 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
                          nets[k]->whd_t, 3 * D, H, tapes[k]->whd_n);
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(H, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
                          nets[k]->wh_t, H, H, tapes[k]->wh_n);
-      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(2 * D, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
-                         nets[k]->w1_t, H, 2 * D, tapes[k]->w1_n);
+      const int Kin = nets[k]->Ka + nets[k]->Kb;
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(Kin, 32), (unsigned)ceil_div(H, 32)), tb, 0, s,
+                         nets[k]->w1_t, H, Kin, tapes[k]->w1_n);
       L2HMC_CHECK_LAUNCH("transpose");
     }
   }
@@ -1022,7 +1086,7 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     a.dcs_part = t.dcs_part; a.dcq_part = t.dcq_part; a.deps_part = w.eps_part;
     hipLaunchKernelGGL(update_bwd_kernel, dim3((unsigned)nblk), dim3(ublock), 0, s, a);
     L2HMC_CHECK_LAUNCH("update_bwd");
-    return call_backward_data(net, t, call, rows, w, s);
+    return call_backward_data(plan, net, t, call, rows, w, s);
   };
   for (int step = N - 1; step >= 0; --step) {
     const int sf = step, sb = N - 1 - step;
@@ -1058,7 +1122,8 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     const l2hmc_dense_grads* g = gr[k];
     L2HMC_REQUIRE(g->w1_t && g->wt && g->b1 && g->wh_t && g->bh && g->whd_t && g->bhd && g->coeff_s && g->coeff_q,
                   "train_backward: NULL gradient pointer");
-    if (int e = gemm_tn(t.d1, H, t.in, 2 * D, Rt, g->w1_t, w, s)) return e;
+    const int Kin = nets[k]->Ka + nets[k]->Kb;
+    if (int e = gemm_tn(t.d1, H, conv ? t.feat : t.in, Kin, Rt, g->w1_t, w, s)) return e;
     if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
     if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
     if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
@@ -1069,6 +1134,31 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcq_part,
                        (int)nblk, (int64_t)D, g->coeff_q);
     L2HMC_CHECK_LAUNCH("reduce_partials");
+  }
+  if (conv) {
+    const l2hmc_conv3d_front* fr[2] = {&plan->xfront, &plan->vfront};
+    const l2hmc_conv3d_grads* gf[2] = {gxf, gvf};
+    for (int k = 0; k < 2; ++k) {
+      const int F = fr[k]->F;
+      const size_t ps = conv3d_bwd_part_floats(F);
+      const int nwg = (int)ceil_div(rows, conv3d_cpw(plan->T, plan->X, F));
+      const l2hmc_conv3d_grads* g = gf[k];
+      L2HMC_REQUIRE(g->w1_a && g->b1_a && g->w2_a && g->b2_a && g->w1_b && g->b1_b && g->w2_b && g->b2_b,
+                    "train_backward: NULL conv gradient pointer");
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(2 * ps, 64)), dim3(256), 0, s,
+                         tapes[k]->conv_part, nwg, (int64_t)(2 * ps), w.part);
+      L2HMC_CHECK_LAUNCH("reduce_partials");
+      float* dst[8] = {g->w1_a, g->b1_a, g->w2_a, g->b2_a, g->w1_b, g->b1_b, g->w2_b, g->b2_b};
+      const size_t len[4] = {(size_t)18 * F, (size_t)F, (size_t)16 * F * F, (size_t)2 * F};
+      size_t off = 0;
+      for (int q = 0; q < 8; ++q) {
+        if (hipMemcpyAsync(dst[q], w.part + off, sizeof(float) * len[q & 3], hipMemcpyDeviceToDevice, s) != hipSuccess) {
+          set_error("train_backward: copy failed");
+          return L2HMC_ERR_HIP;
+        }
+        off += len[q & 3];
+      }
+    }
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, w.eps_part, (int)nblk, (int64_t)1, deps);
   L2HMC_CHECK_LAUNCH("reduce_partials");

@@ -32,8 +32,8 @@ class GaugeTrainer:
         if dynamics.hmc:
             raise ValueError("hmc=True dynamics have no trainable networks (gauge_model.py:913-918 builds the "
                              "sampler only)")
-        if dynamics.network_arch != 'generic':
-            raise NotImplementedError("training is implemented for network_arch='generic'")
+        if dynamics.network_arch not in ('generic', 'conv3D'):
+            raise NotImplementedError("training is implemented for network_arch 'generic' and 'conv3D'")
         self.dynamics = dyn = dynamics
         self.metric, self.loss_scale = metric, float(loss_scale)
         self.weights = dict(aux_weight=float(aux_weight), std_weight=float(std_weight),
@@ -57,11 +57,13 @@ class GaugeTrainer:
         self._eps_dev = torch.tensor([float(dyn.eps)], dtype=torch.float32, device=dev)
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = _lib.Workspace()
-        self._grad_structs = []
+        self._grad_structs, self._conv_grad_structs = [], []
         off = 0
-        for (flat, views, offsets) in flats:
-            st = _lib.DenseGrads(**{k: self.grads.data_ptr() + 4 * (off + offsets[k][0]) for k in offsets})
-            self._grad_structs.append(st)
+        for net, (flat, views, offsets) in zip(self._nets, flats):
+            at = lambda k: self.grads.data_ptr() + 4 * (off + offsets[k][0])     # noqa: E731
+            self._grad_structs.append(_lib.DenseGrads(**{k: at(k) for k in net.SEGMENTS}))
+            conv = [k for k in offsets if k not in net.SEGMENTS]
+            self._conv_grad_structs.append(_lib.Conv3DGrads(**{k: at(k) for k in conv}) if conv else None)
             off += flat.numel()
 
     # ---- views ----------------------------------------------------------------
@@ -123,6 +125,8 @@ class GaugeTrainer:
         _lib.check(L.l2hmc_gauge_train_backward(C.byref(plan), float(beta), dirs.data_ptr(), R, dxN.data_ptr(),
                                                 dvN.data_ptr(), dld.data_ptr(), C.byref(self._grad_structs[0]),
                                                 C.byref(self._grad_structs[1]),
+                                                *(C.byref(g) if g is not None else None
+                                                  for g in self._conv_grad_structs),
                                                 self.grads.data_ptr() + 4 * (n0 + n1), ws, nb, s))
         buf = torch.stack([terms.sum(dtype=torch.float32),
                            torch.full((), float(B), dtype=torch.float32, device=dev)])

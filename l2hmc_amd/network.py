@@ -118,16 +118,24 @@ class _DenseSTQ:
         sync_reference_layout()."""
         if getattr(self, "_flat", None) is None:
             bufs = self._pack_tensors()
-            flat = torch.cat([bufs[k].reshape(-1) for k in self.SEGMENTS])
+            extra = self._extra_flat_tensors()
+            bufs.update(extra)
+            order = self.SEGMENTS + tuple(extra)
+            flat = torch.cat([bufs[k].reshape(-1) for k in order])
             views, offsets, off = {}, {}, 0
-            for k in self.SEGMENTS:
+            for k in order:
                 n = bufs[k].numel()
                 views[k] = flat[off:off + n].view(bufs[k].shape)
                 offsets[k] = (off, off + n)
                 off += n
             self._flat = (flat, views, offsets)
             self._packed = None
+            self._front = None
         return self._flat
+
+    def _extra_flat_tensors(self):
+        """Further trainable tensors appended to the flat buffer (ConvNet3D: the Conv3D kernels / biases)."""
+        return {}
 
     def refresh_packed(self):
         """After the flat buffer changed: rebuild the fragment-ordered image of the fused kernel."""
@@ -161,7 +169,8 @@ class _DenseSTQ:
         if self._packed is None:
             la, lb, lt, lh, ls, ltr, lq = self._layers()
             Ka, Kb, H, D = la.kernel.shape[0], lb.kernel.shape[0], lh.kernel.shape[0], ls.kernel.shape[1]
-            bufs = dict(self._flat[1]) if getattr(self, "_flat", None) is not None else self._pack_tensors()
+            bufs = ({k: self._flat[1][k] for k in self.SEGMENTS} if getattr(self, "_flat", None) is not None
+                    else self._pack_tensors())
             st = _lib.DenseNet(D=D, H=H, Ka=Ka, Kb=Kb, q_tanh=self.q_tanh, reserved=0, packed=None,
                                **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
             L = _lib.lib()
@@ -313,18 +322,29 @@ class ConvNet3D(_DenseSTQ):
             layer.kernel, layer.bias = W, b
         self._front = None
 
+    # struct l2hmc_conv3d_front field -> (layer, attribute): *_a = first input (conv_v*), *_b = second (conv_x*)
+    _FRONT = {"w1_a": ("conv_v1", "kernel"), "b1_a": ("conv_v1", "bias"), "w2_a": ("conv_v2", "kernel"),
+              "b2_a": ("conv_v2", "bias"), "w1_b": ("conv_x1", "kernel"), "b1_b": ("conv_x1", "bias"),
+              "w2_b": ("conv_x2", "kernel"), "b2_b": ("conv_x2", "bias")}
+
+    def _extra_flat_tensors(self):
+        return {k: getattr(getattr(self, layer), attr).contiguous() for k, (layer, attr) in self._FRONT.items()}
+
     def pack_front(self):
-        """struct l2hmc_conv3d_front: *_a = first input (conv_v*), *_b = second input (conv_x*)."""
+        """struct l2hmc_conv3d_front over the Keras-layout kernels (or their slices of the flat training buffer)."""
         if self._front is None:
-            t = {k: getattr(self, k) for k in self._conv_names}
-            ptr = lambda x, n: _lib.dev_ptr(x.contiguous(), name=n)   # noqa: E731
-            self._front = _lib.Conv3DFront(
-                F=int(self.num_filters), reserved=0,
-                w1_a=ptr(t["conv_v1"].kernel, "conv_v1"), b1_a=ptr(t["conv_v1"].bias, "conv_v1/b"),
-                w2_a=ptr(t["conv_v2"].kernel, "conv_v2"), b2_a=ptr(t["conv_v2"].bias, "conv_v2/b"),
-                w1_b=ptr(t["conv_x1"].kernel, "conv_x1"), b1_b=ptr(t["conv_x1"].bias, "conv_x1/b"),
-                w2_b=ptr(t["conv_x2"].kernel, "conv_x2"), b2_b=ptr(t["conv_x2"].bias, "conv_x2/b"))
+            flat = getattr(self, "_flat", None)
+            bufs = ({k: flat[1][k] for k in self._FRONT} if flat is not None else self._extra_flat_tensors())
+            self._front = _lib.Conv3DFront(F=int(self.num_filters), reserved=0,
+                                           **{k: _lib.dev_ptr(v, name=k) for k, v in bufs.items()})
+            self._front_bufs = bufs          # keep the tensors alive
         return self._front
+
+    def sync_reference_layout(self):
+        super().sync_reference_layout()
+        if getattr(self, "_flat", None) is not None:
+            for k, (layer, attr) in self._FRONT.items():
+                setattr(getattr(self, layer), attr, self._flat[1][k].clone())
 
     def __call__(self, inputs):
         """conv_net.py:247-280: (scale, translation, transformation) = net([v, x, t])."""

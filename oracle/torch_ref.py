@@ -42,15 +42,40 @@ def generic_net(p, inputs):
     return S, Tr, Q
 
 
+def conv3d_front(p, a, which, T, X):
+    """network/conv_net.py:251-262 for one input (channels_last): reshape_5D -> Conv3D(F,(3,3,2),same,relu) ->
+    MaxPool3D(2,s2,same) -> Conv3D(2F,(2,2,2),same,relu) -> MaxPool3D(same) -> flatten.  Keras conventions as
+    in oracle/nets.py:134-170 ('same' pads floor((k-1)/2) before, the rest after; pooling clips at the border)."""
+    import torch.nn.functional as Fn
+    B = a.shape[0]
+    h = a.reshape(B, 1, T, X, 2)                                    # torch layout [B, C, T, X, depth]
+    w1 = p[f'conv_{which}1/W'].permute(4, 3, 0, 1, 2)               # Keras [kh,kw,kd,Cin,Cout] -> [Cout,Cin,kh,kw,kd]
+    h = torch.relu(Fn.conv3d(Fn.pad(h, (0, 1, 1, 1, 1, 1)), w1, p[f'conv_{which}1/b']))
+    h = Fn.max_pool3d(h, (2, 2, 2))                                 # depth 2 -> 1
+    w2 = p[f'conv_{which}2/W'].permute(4, 3, 0, 1, 2)
+    h = torch.relu(Fn.conv3d(Fn.pad(h, (0, 1, 0, 1, 0, 1)), w2, p[f'conv_{which}2/b']))
+    h = Fn.max_pool3d(h, (2, 2, 1))                                 # depth 1: the 'same' window holds one cell
+    return h.permute(0, 2, 3, 4, 1).reshape(B, -1)                  # flatten over (h, w, depth, channel)
+
+
+def conv3d_net(p, inputs, T, X):
+    v, x, t = inputs
+    return generic_net(p, [conv3d_front(p, v, 'v', T, X), conv3d_front(p, x, 'x', T, X), t])
+
+
 class TorchGaugeModel:
     """Weights and eps are leaf tensors with requires_grad=True."""
 
-    def __init__(self, T, X, num_steps, eps, masks, xnet, vnet):
+    def __init__(self, T, X, num_steps, eps, masks, xnet, vnet, arch='generic'):
+        self.arch = arch
         self.T, self.X, self.N = T, X, num_steps
         self.eps = torch.tensor(float(eps), dtype=torch.float64, requires_grad=True)
         self.mask = torch.tensor(np.asarray(masks), dtype=torch.float64)
         self.xnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in xnet.items()}
         self.vnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in vnet.items()}
+
+    def _net(self, p, inputs):
+        return generic_net(p, inputs) if self.arch == 'generic' else conv3d_net(p, inputs, self.T, self.X)
 
     def parameters(self):
         return [self.eps] + [self.xnet[k] for k in sorted(self.xnet)] + [self.vnet[k] for k in sorted(self.vnet)]
@@ -61,7 +86,7 @@ class TorchGaugeModel:
 
     def _upd_v(self, x, v, beta, t, bwd):
         g = beta * grad_action(x, self.T, self.X)
-        S, Tr, Q = generic_net(self.vnet, [x, g, t])
+        S, Tr, Q = self._net(self.vnet, [x, g, t])
         eps = self.eps
         if not bwd:
             s = S * (0.5 * eps)
@@ -70,7 +95,7 @@ class TorchGaugeModel:
         return torch.exp(s) * (v + 0.5 * eps * (torch.exp(Q * eps) * g - Tr)), s.sum(1)
 
     def _upd_x(self, x, v, t, m, mi, bwd):
-        S, Tr, Q = generic_net(self.xnet, [v, m * x, t])
+        S, Tr, Q = self._net(self.xnet, [v, m * x, t])
         eps = self.eps
         if not bwd:
             s = S * eps

@@ -16,15 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL_G = 2e-4
 
 
-def _setup(L, N, eps, B, regime, metric='cos_diff', seed=7):
+def _setup(L, N, eps, B, regime, metric='cos_diff', seed=7, arch='generic'):
     from l2hmc_amd.gauge_trainer import GaugeTrainer
     T = X = L
     D = 2 * T * X
-    xp, vp = H.gauge_weights(T, X, regime=regime)
-    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
-    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    xp, vp = H.gauge_weights(T, X, regime=regime) if arch == 'generic' else H.conv_weights(T, X, regime=regime)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp, arch=arch)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B, arch=arch)
     tr = GaugeTrainer(dyn, metric=metric, lr_init=1e-3)
-    tm = TorchGaugeModel(T, X, N, eps, orc.mask, xp, vp)
+    tm = TorchGaugeModel(T, X, N, eps, orc.mask, xp, vp, arch=arch)
     rng = np.random.default_rng(seed)
     x = rng.uniform(0, 2 * np.pi, (B, D))
     z = rng.standard_normal((B, D))
@@ -43,7 +43,12 @@ def _ref_grads(tm, x, z, dx, dz, beta, metric, **w):
 def _packed_ref(net):
     """autograd gradients of one network, rearranged into the library's k-contiguous layout."""
     g = {k: v.grad.numpy() for k, v in net.items()}
+    conv = {}
+    if 'conv_v1/W' in g:       # ConvNet3D: Keras-layout kernels; *_a = first input (conv_v*), *_b = second (conv_x*)
+        conv = {"w1_a": g['conv_v1/W'], "b1_a": g['conv_v1/b'], "w2_a": g['conv_v2/W'], "b2_a": g['conv_v2/b'],
+                "w1_b": g['conv_x1/W'], "b1_b": g['conv_x1/b'], "w2_b": g['conv_x2/W'], "b2_b": g['conv_x2/b']}
     return {
+        **conv,
         "w1_t": np.concatenate([g['v_layer/W'], g['x_layer/W']], axis=0).T,
         "wt": g['t_layer/W'],
         "b1": g['v_layer/b'],
@@ -65,7 +70,7 @@ def _compare(tr, tm, tol=TOL_G):
         assert np.allclose(net['v_layer/b'].grad.numpy(), net['x_layer/b'].grad.numpy())
         assert np.allclose(net['v_layer/b'].grad.numpy(), net['t_layer/b'].grad.numpy())
         for k, want in ref.items():
-            got = gv[name][k].cpu().numpy().astype(np.float64)
+            got = gv[name][k].cpu().numpy().astype(np.float64).reshape(want.shape)
             scale = np.abs(want).max()
             assert scale > 0, (name, k)
             worst[f"{name}.{k}"] = float(np.abs(got - want).max() / scale)
@@ -258,3 +263,38 @@ def test_train_loop_anneals_beta_and_keeps_samples_wrapped():
     xs = out["samples"].cpu().numpy()
     assert (xs >= 0).all() and (xs < 2 * np.pi + 1e-6).all()
     assert tr.global_step == 5 and len(set(out["eps"])) > 1                                  # eps is being trained
+
+
+@pytest.mark.parametrize("N,eps,B,regime", [(2, 0.1, 9, "mild"), (3, 0.15, 5, "stress")])
+def test_conv3d_loss_gradients_match_autograd(N, eps, B, regime):
+    """ConvNet3D (the reference's CLI-default architecture, conv_net.py:247-280) at the 8x8 benchmark lattice:
+    gradients of the Conv3D kernels / biases (through both max-pools and relus), the dense trunk and eps."""
+    tr, tm, x, z, dx, dz = _setup(8, N, eps, B, regime, arch='conv3D')
+    loss, *_ = tr.calc_loss_and_grads(x, 2.5, z=z, draws_x=dx, draws_z=dz)
+    want_loss, _ = _ref_grads(tm, x, z, dx, dz, 2.5, 'cos_diff')
+    assert abs(float(loss) - want_loss) <= 2e-4 * max(1., abs(want_loss))
+    worst = _compare(tr, tm)
+    # the dd = 1 slice of the second kernel only multiplies padding
+    gv = tr.grad_views()
+    assert float(gv["xnet"]["w2_a"].reshape(2, 2, 2, 8, 16)[:, :, 1].abs().max()) == 0.0
+    assert "xnet.w1_a" in worst and "vnet.b2_b" in worst
+
+
+def test_conv3d_training_step_updates_filters_and_sampler():
+    tr, tm, x, z, dx, dz = _setup(8, 2, 0.1, 32, "init", arch='conv3D')
+    tr.lr_init = 1e-4
+    dyn = tr.dynamics
+    k0 = dyn.position_fn.flat_params()[1]["w1_a"].clone()
+    losses = [float(tr.train_step(x, 2.0, z=z, draws_x=dx, draws_z=dz)[0]) for _ in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert not torch.equal(k0, dyn.position_fn.flat_params()[1]["w1_a"])
+    xin, v0f, v0b, coin, u = H.gauge_inputs(32, 128)
+    dyn.fused = True
+    a = dyn.apply_transition(xin, 2.0, v0f, v0b, coin, u)
+    dyn.fused = False
+    b = dyn.apply_transition(xin, 2.0, v0f, v0b, coin, u)
+    for s_, t_ in zip(a, b):
+        assert H.relerr(s_.cpu().numpy(), t_.cpu().numpy()) <= 5e-5
+    tr.sync_weights()
+    np.testing.assert_array_equal(dyn.position_fn.conv_v1.kernel.cpu().numpy().reshape(-1),
+                                  dyn.position_fn.flat_params()[1]["w1_a"].cpu().numpy().reshape(-1))
