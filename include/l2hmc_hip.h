@@ -338,6 +338,20 @@ int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const 
                            const int32_t* dir, int64_t rows, float* x_out, float* v_out,
                            float* sumlogdet, float* p_accept, l2hmc_stream_t stream);
 
+/* One training evaluation on the toy targets (mog_model.py:324-363): `rows` = 2B stacked chains (B started at
+ * x, B at z ~ N(0,1); sampler.py:28-55 picks a direction per chain, passed in `dir`), each integrated in its
+ * direction; per chain v = |x0 - x_N|^2 * p + 1e-4, term = scale / v - v / scale, loss = inv_count * sum of all
+ * 2B terms (inv_count = 1/B).  ONE launch runs forward, loss and the whole reverse pass on-chip.
+ * Outputs: x_out, v_out [rows][x_dim] proposals; p_accept, terms [rows]; grads (device, overwritten):
+ * [xnet gradient | vnet gradient | d loss / d eps], each network in the flat order
+ * [w1_t | wt | b1 | wh_t | bh | whd_t | bhd | coeff_s | coeff_q] of struct l2hmc_dense_net
+ * (d loss / d alpha = eps * d loss / d eps, utils/dynamics.py:51-60). */
+size_t l2hmc_small_train_ws_bytes(const l2hmc_small_plan* plan, int64_t rows);
+int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float* x0, const float* v0, const int32_t* dir,
+                           int64_t rows, float scale, float inv_count, float* x_out, float* v_out,
+                           float* p_accept, float* terms, float* grads, void* ws, size_t ws_bytes,
+                           l2hmc_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Counter-based RNG (Philox4x32-10) standing in for tf.random_normal /
  * tf.random_uniform (gauge_dynamics.py:223,246,269).  Same (seed, offset, n)

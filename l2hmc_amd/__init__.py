@@ -9,4 +9,5 @@ from .sampler import propose, tf_accept  # noqa: F401
 from .distributions import GMM, Gaussian, gen_ring, quadratic_gaussian  # noqa: F401
 from .gauge_sampler import GaugeSampler  # noqa: F401
 from .gauge_trainer import GaugeTrainer  # noqa: F401
+from .dynamics_trainer import DynamicsTrainer  # noqa: F401
 from . import stats  # noqa: F401

@@ -100,6 +100,9 @@ _PROTOS = {
     "l2hmc_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _I64, _I64, _P]),
     "l2hmc_mog_energy_grad": (C.c_int, [C.POINTER(MogTarget), _P, _I64, _P, _P, _P]),
     "l2hmc_small_trajectory": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "l2hmc_small_train_ws_bytes": (_SZ, [C.POINTER(SmallPlan), _I64]),
+    "l2hmc_small_train_step": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _F, _F, _P, _P, _P, _P, _P, _P, _SZ,
+                                         _P]),
     "l2hmc_profile_begin": (C.c_int, [_I32]),
     "l2hmc_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "l2hmc_fill_normal": (C.c_int, [_P, _I64, _U64, _U64, _P]),

@@ -74,6 +74,12 @@ class TorchGaugeModel:
         self.xnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in xnet.items()}
         self.vnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in vnet.items()}
 
+    def _force(self, x, beta):
+        return beta * grad_action(x, self.T, self.X)
+
+    def _energy(self, x, beta):
+        return beta * action(x, self.T, self.X)
+
     def _net(self, p, inputs):
         return generic_net(p, inputs) if self.arch == 'generic' else conv3d_net(p, inputs, self.T, self.X)
 
@@ -85,7 +91,7 @@ class TorchGaugeModel:
         return torch.tensor([[np.cos(arg), np.sin(arg)]], dtype=torch.float64).repeat(B, 1)
 
     def _upd_v(self, x, v, beta, t, bwd):
-        g = beta * grad_action(x, self.T, self.X)
+        g = self._force(x, beta)
         S, Tr, Q = self._net(self.vnet, [x, g, t])
         eps = self.eps
         if not bwd:
@@ -126,8 +132,8 @@ class TorchGaugeModel:
         for step in range(self.N):
             x, v, j = self.leapfrog(x, v, beta, step, bwd)
             ld = ld + j
-        h0 = beta * action(x0, self.T, self.X) + 0.5 * (v0 ** 2).sum(1)
-        h1 = beta * action(x, self.T, self.X) + 0.5 * (v ** 2).sum(1)
+        h0 = self._energy(x0, beta) + 0.5 * (v0 ** 2).sum(1)
+        h1 = self._energy(x, beta) + 0.5 * (v ** 2).sum(1)
         p = torch.exp(torch.minimum(h0 - h1 + ld, torch.zeros((), dtype=torch.float64)))
         return x, v, torch.where(torch.isfinite(p), p, torch.zeros_like(p)), ld
 
@@ -168,3 +174,84 @@ class TorchGaugeModel:
         zq = aux_weight * (pz * torch.abs(q_fft(z) - q_fft(x_)) + eps)
         terms = std_loss + charge_weight * (xq + zq)
         return terms.mean(), terms
+
+
+# ---------------------------------------------------------------------------------------------
+# generic Dynamics on the toy targets (utils/dynamics.py:120-319, utils/network.py:89-114,
+# utils/distributions.py:151-158) and the loss of mog_model.py:324-355
+# ---------------------------------------------------------------------------------------------
+def mlp_net(p, inputs):
+    a, b, t = inputs
+    h = (a @ p['embed_1/W'] + p['embed_1/b']) + (b @ p['embed_2/W'] + p['embed_2/b']) \
+        + (t @ p['embed_3/W'] + p['embed_3/b'])
+    h = torch.relu(h)
+    h = torch.relu(h @ p['linear_1/W'] + p['linear_1/b'])
+    S = torch.exp(p['scale_s']) * torch.tanh(h @ p['linear_s/W'] + p['linear_s/b'])
+    Tr = h @ p['linear_t/W'] + p['linear_t/b']
+    Fq = torch.exp(p['scale_f']) * torch.tanh(h @ p['linear_f/W'] + p['linear_f/b'])
+    return S, Tr, Fq
+
+
+class TorchDynamicsModel(TorchGaugeModel):
+    """Same sub-update algebra as the lattice class (the two reference files write identical formulas);
+    differences: MLP with tanh on both S and F, eps = exp(alpha) with alpha the trainable leaf, mixture
+    energy with closed-form gradient (what tf.gradients of :151-158 evaluates to), temperature."""
+
+    def __init__(self, target, num_steps, eps, masks, xnet, vnet, temperature=1.0):
+        self.arch, self.N = 'mlp', num_steps
+        self.alpha = torch.tensor(float(np.log(eps)), dtype=torch.float64, requires_grad=True)
+        self.mask = torch.tensor(np.asarray(masks), dtype=torch.float64)
+        self.xnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in xnet.items()}
+        self.vnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in vnet.items()}
+        self.temperature = float(temperature)
+        if hasattr(target, 'i_sigmas'):             # oracle.dynamics.GMM
+            self.mus = [torch.tensor(m.astype('float32').astype('float64')) for m in target.mus]
+            self.precs = [torch.tensor(s.astype('float64')) for s in target.i_sigmas]
+            self.logc = [float(np.log(c)) for c in target.constants]
+            self.gaussian = False
+        else:                                       # oracle.dynamics.Gaussian
+            self.mus = [torch.tensor(target.mu.astype('float32').astype('float64'))]
+            self.precs = [torch.tensor(target.i_sigma.astype('float32').astype('float64'))]
+            self.logc = [0.0]
+            self.gaussian = True
+
+    @property
+    def eps(self):
+        return torch.exp(self.alpha)
+
+    def _net(self, p, inputs):
+        return mlp_net(p, inputs)
+
+    def _V(self, x):
+        cols = []
+        for mu, P, c in zip(self.mus, self.precs, self.logc):
+            d = x - mu
+            cols.append(-0.5 * torch.einsum('bi,ij,bj->b', d, P, d) + c)
+        return torch.stack(cols, dim=1)
+
+    def _energy(self, x, beta):
+        V = self._V(x)
+        e = -V[:, 0] if self.gaussian else -torch.logsumexp(V, dim=1)
+        return e / self.temperature
+
+    def _force(self, x, beta):
+        w = torch.ones(x.shape[0], 1, dtype=torch.float64) if self.gaussian else torch.softmax(self._V(x), dim=1)
+        g = torch.zeros_like(x)
+        for i, (mu, P) in enumerate(zip(self.mus, self.precs)):
+            g = g + w[:, i:i + 1] * (0.5 * (x - mu) @ (P + P.T))
+        return g / self.temperature
+
+    def propose(self, x, v0f, v0b, bits):
+        xf, vf, pf, _ = self.trajectory(x, v0f, None, False)
+        xb, vb, pb, _ = self.trajectory(x, v0b, None, True)
+        m = bits.double()
+        return m[:, None] * xf + (1 - m)[:, None] * xb, m * pf + (1 - m) * pb
+
+    def mog_loss(self, x, z, draws_x, draws_z, scale):
+        """mog_model.py:336-355."""
+        Lx, px = self.propose(x, draws_x[0], draws_x[1], draws_x[2])
+        Lz, pz = self.propose(z, draws_z[0], draws_z[1], draws_z[2])
+        v1 = ((x - Lx) ** 2).sum(1) * px + 1e-4
+        v2 = ((z - Lz) ** 2).sum(1) * pz + 1e-4
+        loss = scale * ((1.0 / v1).mean() + (1.0 / v2).mean()) + (-v1.mean() - v2.mean()) / scale
+        return loss, Lx, px, Lz, pz

@@ -298,3 +298,86 @@ def test_conv3d_training_step_updates_filters_and_sampler():
     tr.sync_weights()
     np.testing.assert_array_equal(dyn.position_fn.conv_v1.kernel.cpu().numpy().reshape(-1),
                                   dyn.position_fn.flat_params()[1]["w1_a"].cpu().numpy().reshape(-1))
+
+
+# ------------------------------------------------------------------ toy targets (mog_model.py:324-363)
+def _small_setup(kind, H_nodes, N, eps, B, regime, seed=11, temperature=1.0):
+    import l2hmc_amd as la
+    from l2hmc_amd.dynamics_trainer import DynamicsTrainer
+    from oracle import dynamics as od
+    from oracle.torch_ref import TorchDynamicsModel
+    if kind == "mog":
+        tgt_o = H.mog_target_oracle()
+        tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    else:
+        tgt_o = H.scg_target_oracle()
+        tgt = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+    xp, vp = H.mlp_weights(2, H_nodes, regime=regime)
+    masks = od.make_masks(N, 2, np.random.RandomState(3))
+    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=N, eps=eps,
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=H_nodes),
+                      use_temperature=True)
+    dyn.temperature = temperature
+    dyn.set_masks(masks)
+    dyn.XNet.load_state(xp)
+    dyn.VNet.load_state(vp)
+    tr = DynamicsTrainer(dyn, scale=0.1)
+    tm = TorchDynamicsModel(tgt_o, N, eps, masks, xp, vp, temperature=temperature)
+    rng = np.random.default_rng(seed)
+    x = tgt_o.get_samples(B, rng)
+    z = rng.standard_normal((B, 2))
+    mk = lambda: (rng.standard_normal((B, 2)), rng.standard_normal((B, 2)), rng.integers(0, 2, B).astype(np.float64),  # noqa: E731
+                  rng.uniform(size=B))
+    return tr, tm, x, z, mk(), mk()
+
+
+def _mlp_packed_ref(net):
+    g = {k: v.grad.numpy() for k, v in net.items()}
+    return {
+        "w1_t": np.concatenate([g['embed_1/W'], g['embed_2/W']], axis=0).T, "wt": g['embed_3/W'], "b1": g['embed_1/b'],
+        "wh_t": g['linear_1/W'].T, "bh": g['linear_1/b'],
+        "whd_t": np.stack([g['linear_s/W'].T, g['linear_t/W'].T, g['linear_f/W'].T]),
+        "bhd": np.stack([g['linear_s/b'], g['linear_t/b'], g['linear_f/b']]),
+        "coeff_s": g['scale_s'].reshape(-1), "coeff_q": g['scale_f'].reshape(-1),
+    }
+
+
+@pytest.mark.parametrize("kind,H_nodes,N,eps,B,regime,temp", [
+    ("mog", 50, 5, 0.1, 37, "stress", 1.0),        # cfg 2 widths, ragged batch (3 workgroups, one partly empty)
+    ("mog", 50, 10, 0.1, 16, "mild", 2.5),         # full trajectory length, tempered target
+    ("scg", 10, 5, 0.1, 21, "stress", 1.0),        # cfg 1: 16-wide kernel variant, Gaussian target
+])
+def test_toy_target_loss_gradients_match_autograd(kind, H_nodes, N, eps, B, regime, temp):
+    tr, tm, x, z, dx, dz = _small_setup(kind, H_nodes, N, eps, B, regime, temperature=temp)
+    loss, x_out, px = tr.calc_loss_and_grads(x, z=z, draws_x=dx, draws_z=dz)
+    tt = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))   # noqa: E731
+    want, Lx, wpx, Lz, wpz = tm.mog_loss(tt(x), tt(z), tuple(map(tt, dx)), tuple(map(tt, dz)), 0.1)
+    want.backward()
+    assert H.relerr(tr.last_proposals.cpu().numpy(), np.concatenate([Lx.detach().numpy(), Lz.detach().numpy()])) < 1e-5
+    assert np.abs(tr.last_p.cpu().numpy() - np.concatenate([wpx.detach().numpy(), wpz.detach().numpy()])).max() < 2e-5
+    want = float(want.detach())
+    assert abs(float(loss) - want) <= 2e-4 * max(1., abs(want))
+    gv = tr.grad_views()
+    worst = {}
+    for name, net in (("xnet", tm.xnet), ("vnet", tm.vnet)):
+        for k, w in _mlp_packed_ref(net).items():
+            got = gv[name][k].cpu().numpy().astype(np.float64).reshape(w.shape)
+            worst[f"{name}.{k}"] = float(np.abs(got - w).max() / np.abs(w).max())
+    worst["alpha"] = abs(float(gv["alpha"][0]) - float(tm.alpha.grad)) / abs(float(tm.alpha.grad))
+    bad = {k: v for k, v in worst.items() if not v <= TOL_G}
+    assert not bad, f"gradient mismatch: {bad}\nall: {worst}"
+    # accept/reject of the x chains: sampler.py:57-59 (>=)
+    acc = (tr.last_p[:B].cpu().numpy() - dx[3]) >= 0
+    np.testing.assert_allclose(x_out.cpu().numpy()[acc], tr.last_proposals[:B].cpu().numpy()[acc])
+    np.testing.assert_allclose(x_out.cpu().numpy()[~acc], x[~acc].astype(np.float32))
+
+
+def test_toy_target_training_reduces_loss():
+    tr, tm, x, z, dx, dz = _small_setup("mog", 50, 10, 0.1, 256, "init")
+    tr.lr_init = 1e-3
+    losses = [float(tr.train_step(x, z=z, draws_x=dx, draws_z=dz)[0]) for _ in range(10)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert float(tr.dynamics.eps) != pytest.approx(0.1, abs=1e-7)       # alpha is trained
+    # the sampling kernel sees the updated weights
+    X, V, p = tr.dynamics.forward(x)
+    assert torch.isfinite(X).all() and tr.global_step == 10
