@@ -23,20 +23,9 @@
 // buffered one k-chunk (16 k) ahead.  The A operand (16 rows of activations) is
 // shared by the 4 waves and read from LDS with conflict-free ds_read_b128
 // (row stride = K + 8 floats).
-#include "stq_dense.h"
-#include <math.h>
+#include "fused_common.h"
 
 namespace l2hmc {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int kFM = 16;                   // rows per workgroup
-#ifndef L2HMC_FUSED_WAVES
-#define L2HMC_FUSED_WAVES 4
-#endif
-constexpr int kFWaves = L2HMC_FUSED_WAVES;   // waves per workgroup (4 = one per SIMD, 8 = two per SIMD)
-constexpr int kFThreads = 64 * kFWaves;   // wave w owns output columns [w*N/kFWaves, (w+1)*N/kFWaves)
-constexpr int kTPC = kFThreads / kFM;     // threads per chain in the chain-local passes
 
 // D = x_dim, H = hidden width, KA = width of each first-layer input (x_dim for GenericNet; the flattened conv
 // features for ConvNet3D), CONV = the two inputs go through the conv front-end first (8x8 lattice, F = 8).
@@ -64,16 +53,6 @@ struct FusedCfg {
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
                                     2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/ + CONV_FLOATS;
 };
-
-// exp / tanh on the hardware exp2 + rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Arguments here are
-// eps * S, eps * Q and pre-activations of O(1): |error| <= ~2e-7 relative for exp, ~1.5e-7 absolute for
-// tanh -- at the fp32 rounding floor of the quantities they feed, and ~8x cheaper than the libm forms.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(x));      // exp(-2|x|) in (0, 1]
-  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
-  return copysignf(t, x);
-}
 
 // ---------------------------------------------------------------------------
 // weight packing (device side, once per weight update)
@@ -114,66 +93,6 @@ __global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out) {
   }
 }
 
-// ---------------------------------------------------------------------------
-// streaming GEMM core: acc[t] += A(16 x 16*NKC) . Wpacked, one wave, NT tiles
-// ---------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void mfma_block(const f32x4 a, const f32x4 (&b)[NT], f32x4 (&acc)[NT]) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[t][e], acc[t], 0, 0, 0);
-}
-
-template <int NT>
-__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restrict__ wp, int kc) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
-}
-
-// Three-deep ring of B fragments: chunk kc+3 is requested as soon as chunk kc has been consumed, so every
-// load has two full MFMA blocks (~2 x 32 x NT cycles) to come back from L2.  The ring of the NEXT layer is
-// primed before the current layer's epilogue and barrier, which hides the pipeline fill.
-template <int NT>
-struct BRing {
-  f32x4 b[3][NT];
-};
-
-template <int NT>
-__device__ __forceinline__ void ring_prime(BRing<NT>& R, const float* __restrict__ wp) {
-  load_frags<NT>(R.b[0], wp, 0);
-  load_frags<NT>(R.b[1], wp, 1);
-  load_frags<NT>(R.b[2], wp, 2);
-}
-
-// wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
-// (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
-template <int NT, int NKC, typename AF>
-__device__ __forceinline__ void stream_layer(BRing<NT>& R, const float* __restrict__ wp, AF afrag,
-                                             f32x4 (&acc)[NT]) {
-  static_assert(NKC >= 3, "ring depth");
-  f32x4 a0 = afrag(0), a1;
-  int kc = 0;
-#pragma nounroll
-  for (; kc + 3 <= NKC; kc += 3) {
-    a1 = afrag(kc + 1 < NKC ? kc + 1 : NKC - 1);
-    mfma_block<NT>(a0, R.b[0], acc);
-    if (kc + 3 < NKC) load_frags<NT>(R.b[0], wp, kc + 3);
-    a0 = afrag(kc + 2 < NKC ? kc + 2 : NKC - 1);
-    mfma_block<NT>(a1, R.b[1], acc);
-    if (kc + 4 < NKC) load_frags<NT>(R.b[1], wp, kc + 4);
-    a1 = afrag(kc + 3 < NKC ? kc + 3 : NKC - 1);
-    mfma_block<NT>(a0, R.b[2], acc);
-    if (kc + 5 < NKC) load_frags<NT>(R.b[2], wp, kc + 5);
-    a0 = a1;
-  }
-  if constexpr (NKC % 3 >= 1) {
-    if constexpr (NKC % 3 == 2) a1 = afrag(NKC - 1);
-    mfma_block<NT>(a0, R.b[0], acc);
-  }
-  if constexpr (NKC % 3 == 2) mfma_block<NT>(a1, R.b[1], acc);
-}
-
 #ifdef L2HMC_STAMPS
 #define FT_NOW()                                                                              \
   ({                                                                                          \
@@ -206,6 +125,7 @@ struct FusedArgs {
   float* p_accept;                       // [rows] or NULL
   unsigned long long* stamps;            // diagnostic builds only
   int stagger;                           // cycles of start delay per in-XCD workgroup index (0 = none)
+  FusedTape tx, tv;                      // training tape per network (all-NULL = sampling)
 };
 
 #ifdef L2HMC_STAMPS
@@ -213,7 +133,8 @@ int g_fused_stagger = 0;
 extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; }
 #endif
 
-template <int D, int H, int KA, bool CONV>
+// TAPE: training instantiation (GenericNet plans) that also writes the per-call tape of train.hip
+template <int D, int H, int KA, bool CONV, bool TAPE = false>
 __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p) {
   using Cfg = FusedCfg<D, H, KA, CONV>;
   constexpr int SX = Cfg::SX, SH = Cfg::SH, SA = Cfg::SA, NT1 = Cfg::NT1, NTH = Cfg::NTH;
@@ -456,8 +377,33 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   //     3 = compute, snapshot the first-input half into keep_x; 4 = start from keep_x, second half only.
   auto net_update = [&](const l2hmc_dense_net& net, const float* cn, const float* in1, int mode, int sub,
                         bool prep_next_mask, int l1, bool is_vnet, const float (&tcr)[4],
-                        const float (&tsr)[4]) {
+                        const float (&tsr)[4], int callidx) {
     const float* pk = net.packed;
+    // training tape (generic plans): this call's inputs and the state its sub-update consumes
+    [[maybe_unused]] const FusedTape& tp = is_vnet ? p.tv : p.tx;
+    [[maybe_unused]] const size_t tcr0 = (size_t)callidx * (size_t)p.rows + (size_t)row0;     // first taped row of this workgroup
+    if constexpr (TAPE) {
+      {
+        const float* stsrc = mode == 1 ? vs : xs;
+        for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
+          const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
+          if (rr < nrow) {
+            float* dst = tp.in + (tcr0 + rr) * (2 * D);
+            *reinterpret_cast<f32x4*>(dst + c4) = *reinterpret_cast<const f32x4*>(in1 + rr * SX + c4);
+            *reinterpret_cast<f32x4*>(dst + D + c4) = *reinterpret_cast<const f32x4*>(gs + rr * SX + c4);
+            *reinterpret_cast<f32x4*>(tp.st + (tcr0 + rr) * D + c4) =
+                *reinterpret_cast<const f32x4*>(stsrc + rr * SX + c4);
+          }
+        }
+      }
+    }
+    [[maybe_unused]] auto tape_rows = [&](float* dst, const float* src) {     // [16][H] LDS rows -> tape
+      for (int i = tid; i < kFM * (H / 4); i += kFThreads) {
+        const int rr = i / (H / 4), c4 = (i - rr * (H / 4)) * 4;
+        if (rr < nrow)
+          *reinterpret_cast<f32x4*>(dst + (tcr0 + rr) * H + c4) = *reinterpret_cast<const f32x4*>(src + rr * SH + c4);
+      }
+    };
     const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
     const float* wp2 = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
     const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
@@ -529,6 +475,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       __syncthreads();
       FT_ADD(6, tb);
     }
+    if constexpr (TAPE) tape_rows(tp.h1, h1);
     // ----- layer 2
     {
       f32x4 acc[NT1];
@@ -555,6 +502,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       __syncthreads();
       FT_ADD(6, tb);
     }
+    if constexpr (TAPE) tape_rows(tp.h2, h2);
     // ----- heads + update
     {
       f32x4 acc[3 * NTH];
@@ -585,6 +533,15 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
           float Q = acc[2 * NTH + t][e] + b_q;
           Q = (net.q_tanh ? fast_tanh(Q) : Q) * e_q;
           const int idx = row * SX + col;
+          if constexpr (TAPE) {
+            if (row < nrow) {
+              const size_t plane = (size_t)p.rows * D;
+              float* o = tp.stq + (size_t)callidx * 3 * plane + ((size_t)row0 + row) * D + col;
+              o[0] = S;
+              o[plane] = Tt;
+              o[2 * plane] = Q;
+            }
+          }
           if (mode == 1) {
             // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
             const float g = gs[idx], v = vs[idx];
@@ -664,7 +621,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       // call 2: position sub-update 2                          call 3: second momentum half-kick (product kept)
       const int l1 = call == 0 ? (keep_v_valid ? 2 : 0) : call == 1 ? 3 : call == 2 ? 4 : 1;
       net_update(is_v ? p.vnet : p.xnet, is_v ? cv : cx, is_v ? xs : vs, is_v ? 1 : 2, call == 2 ? 1 : 0,
-                 call < 2, l1, is_v, tcr, tsr);
+                 call < 2, l1, is_v, tcr, tsr, 2 * step + (call == 0 || call == 1 ? 0 : 1));
     }
     keep_v_valid = true;
   }
@@ -728,7 +685,8 @@ int fused_plan_supported(const l2hmc_gauge_plan* p) {
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
                             float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
-                            hipStream_t stream, int64_t x_mod, int64_t dir_split) {
+                            hipStream_t stream, int64_t x_mod, int64_t dir_split, const FusedTape* tape_x,
+                            const FusedTape* tape_v) {
   const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   using CfgG = FusedCfg<128, 512, 128, false>;
   using CfgC = FusedCfg<128, 256, 64, true>;
@@ -753,6 +711,25 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
   a.x_mod = x_mod; a.dir_split = dir_split;
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
+  const bool tape = tape_x && tape_v;
+  if (tape) {
+    L2HMC_REQUIRE(!conv && step_begin == 0, "fused trajectory: taping needs a GenericNet plan and the whole trajectory");
+    L2HMC_REQUIRE(tape_x->in && tape_x->h1 && tape_x->h2 && tape_x->stq && tape_x->st && tape_v->in && tape_v->h1 &&
+                      tape_v->h2 && tape_v->stq && tape_v->st,
+                  "fused trajectory: NULL tape pointer");
+    a.tx = *tape_x;
+    a.tv = *tape_v;
+    static bool tape_attr = false;
+    if (!tape_attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess) {
+        set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
+        return L2HMC_ERR_HIP;
+      }
+      tape_attr = true;
+    }
+  }
 #ifdef L2HMC_STAMPS
   a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
   a.stagger = g_fused_stagger;
@@ -761,6 +738,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   prof_before(kProfFused, stream);
   if (conv)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(kFThreads), lds, stream, a);
+  else if (tape)
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(kFThreads), lds, stream, a);
   else
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(kFThreads), lds, stream, a);
   prof_after(kProfFused, stream);

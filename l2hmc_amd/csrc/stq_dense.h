@@ -108,10 +108,28 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
 int launch_heads(HeadsArgs& a, hipStream_t stream);
 int dense_net_supported(const l2hmc_dense_net* n);
 int fused_plan_supported(const l2hmc_gauge_plan* p);
+// Optional tape of the whole-trajectory kernel for the training path (train.hip): per network, every call's
+// first-layer input [a | b*mask], hidden activations, (S, T, Q) planes and the state the sub-update consumed,
+// laid out [call][rows][.] exactly as the layered taped forward writes them.  NULL pointers = no taping.
+struct FusedTape {
+  float* in;    // [calls][rows][2D]
+  float* h1;    // [calls][rows][H]
+  float* h2;    // [calls][rows][H]
+  float* stq;   // [calls][3][rows][D]
+  float* st;    // [calls][rows][D]
+};
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,
                             float* v_out, float* logdet, int logdet_accumulate, float* p_accept,
-                            hipStream_t stream, int64_t x_mod = 0, int64_t dir_split = 0);
+                            hipStream_t stream, int64_t x_mod = 0, int64_t dir_split = 0,
+                            const FusedTape* tape_x = nullptr, const FusedTape* tape_v = nullptr);
+// whole-trajectory reverse pass (fused_train.hip); deltas_*: {dout, d2, d1} tapes, coef_parts: {dcs_x, dcq_x, dcs_v, dcq_v}
+size_t fused_bwd_pack_floats(const l2hmc_dense_net* n);
+int fused_train_supported(const l2hmc_gauge_plan* p);
+int launch_fused_train_backward(const l2hmc_gauge_plan* p, float beta, const int* dir, int64_t rows, float* dx,
+                                float* dv, const float* dld, const FusedTape& tx, const FusedTape& tv,
+                                float* const deltas_x[3], float* const deltas_v[3], float* pack_x, float* pack_v,
+                                float* const coef_parts[4], float* deps_part, hipStream_t stream);
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream);
 

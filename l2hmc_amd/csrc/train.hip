@@ -24,6 +24,7 @@
 //  * every reduction runs in a fixed order (no float atomics): results are reproducible.
 #include "stq_dense.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -690,6 +691,7 @@ struct NetTape {
   float *in, *h1, *h2, *stq, *st, *d1, *d2, *dout;   // [calls][rows][.]
   float *dcs_part, *dcq_part;                         // [nblk][D]
   float *w1_n, *wh_n, *whd_n;                         // weights transposed for the backward-data products
+  float *bpack;                                       // fragment-ordered transposed weights (fused reverse pass)
   float *feat;                                        // ConvNet3D: [calls][rows][Ka+Kb] front-end features
   float *conv_part;                                   // ConvNet3D: [workgroups][2][filter-gradient slot]
 };
@@ -701,6 +703,20 @@ struct TrainWs {
 
 static inline int64_t imax64(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
+static bool train_fused_forward() {
+  static const int mode = [] {
+    const char* e = getenv("L2HMC_TRAIN_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  return mode != 0;
+}
+static bool train_fused_backward() {
+  static const int mode = [] {
+    const char* e = getenv("L2HMC_TRAIN_FUSED_BWD");
+    return e ? atoi(e) : 1;
+  }();
+  return mode != 0;
+}
 static int64_t upd_blocks(int64_t rows) { return ceil_div(rows, kUpdRows); }
 static int tn_splits(int mt, int nt, int64_t R) {
   int s = (int)imax64(1, 512 / ((int64_t)mt * nt));
@@ -745,6 +761,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     t.conv_part = conv ? take((size_t)ceil_div(rows, conv3d_cpw(p->T, p->X, fronts[k]->F)) * 2 *
                               conv3d_bwd_part_floats(fronts[k]->F))
                        : nullptr;
+    t.bpack = take(fused_bwd_pack_floats(nets[k]));
     t.w1_n = take((size_t)Kin * H);
     t.wh_n = take((size_t)H * H);
     t.whd_n = take((size_t)3 * D * H);
@@ -976,6 +993,11 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
   L2HMC_CHECK_LAUNCH("invert_mask");
   float* x = x_out;
   float* v = v_out;
+  if (train_fused_forward() && fused_train_supported(plan)) {
+    // whole-trajectory kernel (fused_traj.hip) writing the same tape: one launch instead of ~6 per network call
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st};
+    return launch_fused_trajectory(plan, beta, 0, N, x, v, dir, rows, x, v, sumlogdet, 0, p_accept, s, 0, 0, &tx, &tv);
+  }
   if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, w.act0, nullptr, nullptr, nullptr, s)) return e;
   if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin0, stream)) return e;
   for (int step = 0; step < N; ++step) {
@@ -1088,25 +1110,39 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     L2HMC_CHECK_LAUNCH("update_bwd");
     return call_backward_data(plan, net, t, call, rows, w, s);
   };
-  for (int step = N - 1; step >= 0; --step) {
-    const int sf = step, sb = N - 1 - step;
-    const float* m_f = plan->masks + (size_t)sf * D;
-    const float* m_b = plan->masks + (size_t)sb * D;
-    const float* mi_f = w.mask_inv + (size_t)sf * D;
-    const float* mi_b = w.mask_inv + (size_t)sb * D;
-    for (int half = 1; half >= 0; --half) {
-      const int vc = 2 * step + half;
-      if (int e = upd(&plan->vnet, w.v, vc, 1, nullptr, nullptr)) return e;
-      hipLaunchKernelGGL(vnet_in_bwd_kernel, dim3(rgrid), dim3(256), vlds, s, w.din,
-                         w.dg, w.v.in + (size_t)vc * rows * 2 * D, beta, plan->T, plan->X, rows, dx);
-      L2HMC_CHECK_LAUNCH("vnet_in_bwd");
-      if (half == 1) {
-        for (int sub = 1; sub >= 0; --sub) {
-          const float* kf = sub == 0 ? m_f : mi_f;
-          const float* kb = sub == 0 ? mi_b : m_b;
-          if (int e = upd(&plan->xnet, w.x, 2 * step + sub, 2, kf, kb)) return e;
-          hipLaunchKernelGGL(xnet_in_bwd_kernel, dim3(rgrid), dim3(256), 0, s, w.din, kf, kb, dir, rows, D, dx, dv);
-          L2HMC_CHECK_LAUNCH("xnet_in_bwd");
+  const bool fused_bwd = train_fused_backward() && fused_train_supported(plan);
+  int64_t ncoef = nblk;            // workgroups that wrote coefficient / step-size partials
+  if (fused_bwd) {
+    // one launch for the whole reverse data path (fused_train.hip)
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st};
+    float* const dxs_[3] = {w.x.dout, w.x.d2, w.x.d1};
+    float* const dvs_[3] = {w.v.dout, w.v.d2, w.v.d1};
+    float* const coef[4] = {w.x.dcs_part, w.x.dcq_part, w.v.dcs_part, w.v.dcq_part};
+    if (int e = launch_fused_train_backward(plan, beta, dir, rows, dx, dv, dlogdet, tx, tv, dxs_, dvs_, w.x.bpack,
+                                            w.v.bpack, coef, w.eps_part, s))
+      return e;
+    ncoef = ceil_div(rows, 16);
+  } else {
+    for (int step = N - 1; step >= 0; --step) {
+      const int sf = step, sb = N - 1 - step;
+      const float* m_f = plan->masks + (size_t)sf * D;
+      const float* m_b = plan->masks + (size_t)sb * D;
+      const float* mi_f = w.mask_inv + (size_t)sf * D;
+      const float* mi_b = w.mask_inv + (size_t)sb * D;
+      for (int half = 1; half >= 0; --half) {
+        const int vc = 2 * step + half;
+        if (int e = upd(&plan->vnet, w.v, vc, 1, nullptr, nullptr)) return e;
+        hipLaunchKernelGGL(vnet_in_bwd_kernel, dim3(rgrid), dim3(256), vlds, s, w.din,
+                           w.dg, w.v.in + (size_t)vc * rows * 2 * D, beta, plan->T, plan->X, rows, dx);
+        L2HMC_CHECK_LAUNCH("vnet_in_bwd");
+        if (half == 1) {
+          for (int sub = 1; sub >= 0; --sub) {
+            const float* kf = sub == 0 ? m_f : mi_f;
+            const float* kb = sub == 0 ? mi_b : m_b;
+            if (int e = upd(&plan->xnet, w.x, 2 * step + sub, 2, kf, kb)) return e;
+            hipLaunchKernelGGL(xnet_in_bwd_kernel, dim3(rgrid), dim3(256), 0, s, w.din, kf, kb, dir, rows, D, dx, dv);
+            L2HMC_CHECK_LAUNCH("xnet_in_bwd");
+          }
         }
       }
     }
@@ -1130,9 +1166,9 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
     if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcs_part,
-                       (int)nblk, (int64_t)D, g->coeff_s);
+                       (int)ncoef, (int64_t)D, g->coeff_s);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcq_part,
-                       (int)nblk, (int64_t)D, g->coeff_q);
+                       (int)ncoef, (int64_t)D, g->coeff_q);
     L2HMC_CHECK_LAUNCH("reduce_partials");
   }
   if (conv) {
@@ -1160,7 +1196,7 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
       }
     }
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, w.eps_part, (int)nblk, (int64_t)1, deps);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, w.eps_part, (int)ncoef, (int64_t)1, deps);
   L2HMC_CHECK_LAUNCH("reduce_partials");
   return L2HMC_OK;
 }

@@ -81,13 +81,16 @@ def _compare(tr, tm, tol=TOL_G):
     return worst
 
 
-@pytest.mark.parametrize("L,N,eps,B,regime", [
-    (4, 3, 0.2, 6, "mild"),
-    (4, 2, 0.15, 37, "stress"),       # ragged batch, strong S/Q
-    (8, 2, 0.1, 16, "mild"),          # benchmark widths D=128, H=512
+@pytest.mark.parametrize("L,N,eps,B,regime,fused", [
+    (4, 3, 0.2, 6, "mild", True),
+    (4, 2, 0.15, 37, "stress", True),       # ragged batch, strong S/Q
+    (8, 2, 0.1, 16, "mild", True),          # benchmark widths D=128, H=512: whole-trajectory forward + reverse kernels
+    (8, 3, 0.1, 9, "mild", True),           # ... with a partly filled 16-row tile (18 rows)
+    (8, 2, 0.1, 16, "mild", False),         # same widths through the layered kernels
 ])
-def test_loss_gradients_match_autograd(L, N, eps, B, regime):
+def test_loss_gradients_match_autograd(L, N, eps, B, regime, fused):
     tr, tm, x, z, dx, dz = _setup(L, N, eps, B, regime)
+    tr.dynamics.fused = fused
     beta = 2.5
     loss, x_out, px, x_dq = tr.calc_loss_and_grads(x, beta, z=z, draws_x=dx, draws_z=dz)
     want_loss, want_terms = _ref_grads(tm, x, z, dx, dz, beta, 'cos_diff')
