@@ -16,6 +16,7 @@
 // is the plaquette stencil with sin P -> cos P . P[u], chain-local in LDS.
 // All reductions have a fixed order: results are reproducible.
 #include "fused_common.h"
+#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
   using Cfg = FusedBwdCfg<D, H>;
   constexpr int SX = Cfg::SX, SO = Cfg::SO, SH = Cfg::SH, NT1 = Cfg::NT1, NT3 = Cfg::NT3, SP = Cfg::SP;
   constexpr int sites = D / 2;
+  static_assert(NT1 <= 8, "relu masks are one 32-bit word per lane");
   static_assert(kTPC * 8 == D, "phase A maps 16 threads x 8 columns onto a chain");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* dxs = lds;                       // [16][SX] d loss / d x
@@ -164,6 +166,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       const int q_tanh = is_v ? p.qtanh_v : p.qtanh_x;
       float* dout_t = is_v ? p.dout_v : p.dout_x;
 
+      // relu masks of this call's h1 / h2, written by the taped forward kernel in this lane's fragment order
+      const unsigned gate1 = tp.gate[((size_t)(cidx * 2 + 0) * gridDim.x + blockIdx.x) * kFThreads + tid];
+      const unsigned gate2 = tp.gate[((size_t)(cidx * 2 + 1) * gridDim.x + blockIdx.x) * kFThreads + tid];
       // ================= phase A: the sub-update, element-wise (gauge_dynamics.py:486-590 differentiated)
       {
         float S[8], Tt[8], Q[8], st[8], ia[8], ib[8];
@@ -293,9 +298,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           const int col = (wave * NT1 + t) * 16 + r;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int row = q * 4 + e;
-            const float gate = row < nrow ? tp.h2[(tcr0 + row) * H + col] : 0.f;
-            d2s[row * SH + col] = gate > 0.f ? acc[t][e] : 0.f;
+            d2s[(q * 4 + e) * SH + col] = ((gate2 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
           }
         }
       }
@@ -317,9 +320,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           const int col = (wave * NT1 + t) * 16 + r;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int row = q * 4 + e;
-            const float gate = row < nrow ? tp.h1[(tcr0 + row) * H + col] : 0.f;
-            d1s[row * SH + col] = gate > 0.f ? acc[t][e] : 0.f;
+            d1s[(q * 4 + e) * SH + col] = ((gate1 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
           }
         }
       }

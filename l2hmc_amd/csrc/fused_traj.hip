@@ -36,7 +36,7 @@ struct FusedCfg {
   static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
   static constexpr int NT1 = H / (16 * kFWaves);   // 16-column tiles per wave, layers 1 and 2
   static constexpr int NTH = D / (16 * kFWaves);   // tiles per wave per head
-  static_assert(NT1 >= 1 && NTH >= 1, "every wave needs at least one tile per layer");
+  static_assert(NT1 >= 1 && NT1 <= 8 && NTH >= 1, "every wave needs at least one tile per layer");
   static constexpr int KC1 = 2 * KA / 16;      // k-chunks (16 k each), layer 1
   static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
   static constexpr size_t P1 = (size_t)2 * KA * H;  // packed floats per section
@@ -460,14 +460,19 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       ring_prime<NT1>(R2, wp2);      // layer-2 weights start flowing under the epilogue + barrier
       FT_ADD(0, t0);
       t0 = FT_NOW();
+      [[maybe_unused]] unsigned gmask = 0;
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
         const int col = (wave * NT1 + t) * 16 + r;
         const float b = cn[col], w0 = cn[H + col], w1 = cn[2 * H + col];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          h1[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b + (tcr[e] * w0 + tsr[e] * w1), 0.f);
+        for (int e = 0; e < 4; ++e) {
+          const float hv = fmaxf(acc[t][e] + b + (tcr[e] * w0 + tsr[e] * w1), 0.f);
+          h1[(q * 4 + e) * SH + col] = hv;
+          if constexpr (TAPE) gmask |= (hv > 0.f ? 1u : 0u) << (t * 4 + e);
+        }
       }
+      if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 0) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
       FT_ADD(3, t0);
     }
     {
@@ -488,13 +493,19 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       ring_prime<3 * NTH>(R3, wph);
       FT_ADD(1, t0);
       t0 = FT_NOW();
+      [[maybe_unused]] unsigned gmask = 0;
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
         const int col = (wave * NT1 + t) * 16 + r;
         const float b = cn[3 * H + col];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h2[(q * 4 + e) * SH + col] = fmaxf(acc[t][e] + b, 0.f);
+        for (int e = 0; e < 4; ++e) {
+          const float hv = fmaxf(acc[t][e] + b, 0.f);
+          h2[(q * 4 + e) * SH + col] = hv;
+          if constexpr (TAPE) gmask |= (hv > 0.f ? 1u : 0u) << (t * 4 + e);
+        }
       }
+      if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 1) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
       FT_ADD(4, t0);
     }
     {
@@ -715,7 +726,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   if (tape) {
     L2HMC_REQUIRE(!conv && step_begin == 0, "fused trajectory: taping needs a GenericNet plan and the whole trajectory");
     L2HMC_REQUIRE(tape_x->in && tape_x->h1 && tape_x->h2 && tape_x->stq && tape_x->st && tape_v->in && tape_v->h1 &&
-                      tape_v->h2 && tape_v->stq && tape_v->st,
+                      tape_v->h2 && tape_v->stq && tape_v->st && tape_x->gate && tape_v->gate,
                   "fused trajectory: NULL tape pointer");
     a.tx = *tape_x;
     a.tv = *tape_v;

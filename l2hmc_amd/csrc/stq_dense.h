@@ -117,6 +117,8 @@ struct FusedTape {
   float* h2;    // [calls][rows][H]
   float* stq;   // [calls][3][rows][D]
   float* st;    // [calls][rows][D]
+  unsigned* gate;   // [calls][2 layers][workgroups][256 threads]: relu masks of h1 / h2 in the lane's own C-fragment
+                    // order (bit t*4+e), so the fused reverse pass gates its deltas with one 4-byte load per layer
 };
 int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begin, int step_end,
                             const float* x0, const float* v0, const int* dir, int64_t rows, float* x_out,

@@ -692,6 +692,7 @@ struct NetTape {
   float *dcs_part, *dcq_part;                         // [nblk][D]
   float *w1_n, *wh_n, *whd_n;                         // weights transposed for the backward-data products
   float *bpack;                                       // fragment-ordered transposed weights (fused reverse pass)
+  unsigned *gate;                                     // relu masks in fragment order (fused kernels)
   float *feat;                                        // ConvNet3D: [calls][rows][Ka+Kb] front-end features
   float *conv_part;                                   // ConvNet3D: [workgroups][2][filter-gradient slot]
 };
@@ -762,6 +763,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
                               conv3d_bwd_part_floats(fronts[k]->F))
                        : nullptr;
     t.bpack = take(fused_bwd_pack_floats(nets[k]));
+    t.gate = reinterpret_cast<unsigned*>(take((size_t)C * 2 * ceil_div(rows, 16) * 256));
     t.w1_n = take((size_t)Kin * H);
     t.wh_n = take((size_t)H * H);
     t.whd_n = take((size_t)3 * D * H);
@@ -995,7 +997,7 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
   float* v = v_out;
   if (train_fused_forward() && fused_train_supported(plan)) {
     // whole-trajectory kernel (fused_traj.hip) writing the same tape: one launch instead of ~6 per network call
-    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st};
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.gate};
     return launch_fused_trajectory(plan, beta, 0, N, x, v, dir, rows, x, v, sumlogdet, 0, p_accept, s, 0, 0, &tx, &tv);
   }
   if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, w.act0, nullptr, nullptr, nullptr, s)) return e;
@@ -1110,11 +1112,11 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     L2HMC_CHECK_LAUNCH("update_bwd");
     return call_backward_data(plan, net, t, call, rows, w, s);
   };
-  const bool fused_bwd = train_fused_backward() && fused_train_supported(plan);
+  const bool fused_bwd = train_fused_forward() && train_fused_backward() && fused_train_supported(plan);
   int64_t ncoef = nblk;            // workgroups that wrote coefficient / step-size partials
   if (fused_bwd) {
     // one launch for the whole reverse data path (fused_train.hip)
-    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st};
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.gate};
     float* const dxs_[3] = {w.x.dout, w.x.d2, w.x.d1};
     float* const dvs_[3] = {w.v.dout, w.v.d2, w.v.d1};
     float* const coef[4] = {w.x.dcs_part, w.x.dcq_part, w.v.dcs_part, w.v.dcq_part};
