@@ -4,6 +4,8 @@ the step size, through the C ABI, against torch.autograd on the float64 restatem
 Tolerance: the forward path meets north_star's 1e-5; gradients are sums of ~1e5 fp32 products through up to
 4N chained network calls, so they are compared per tensor in the max norm relative to the tensor's own largest
 entry at 2e-4 (measured: 1e-6..3e-5)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -384,3 +386,73 @@ def test_toy_target_training_reduces_loss():
     # the sampling kernel sees the updated weights
     X, V, p = tr.dynamics.forward(x)
     assert torch.isfinite(X).all() and tr.global_step == 10
+
+
+# ------------------------------------------------------------------ committed fixtures (tests/golden/train_*.npz)
+def test_lattice_gradients_match_committed_fixture():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_L8_generic.npz"))
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    T, X, N = int(g["T"]), int(g["X"]), int(g["num_steps"])
+    xp, vp = H.gauge_weights(T, X, seed=106, regime=str(g["regime"]))
+    dyn = H.gauge_hip(T, X, N, float(g["eps"]), xp, vp, g["masks"], g["x"].shape[0])
+    tr = GaugeTrainer(dyn)
+    dx = tuple(g[f"draws_x/{i}"] for i in range(4))
+    dz = tuple(g[f"draws_z/{i}"] for i in range(4))
+    loss, *_ = tr.calc_loss_and_grads(g["x"], float(g["beta"]), z=g["z"], draws_x=dx, draws_z=dz)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-4)
+    np.testing.assert_allclose(tr.last_loss_terms.cpu().numpy(), g["terms"], rtol=2e-4,
+                               atol=1e-5 * np.abs(g["terms"]).max())
+    gv = tr.grad_views()
+    assert float(gv["eps"][0]) == pytest.approx(float(g["grad_eps"]), rel=TOL_G)
+    D, Hh = 2 * T * X, 4 * 2 * T * X
+    for name in ("xnet", "vnet"):
+        v = {k: t.cpu().numpy().astype(np.float64) for k, t in gv[name].items()}
+        # small tensors are stored in full
+        np.testing.assert_allclose(v["b1"], g[f"{name}/v_layer/b"], rtol=0, atol=TOL_G * np.abs(g[f"{name}/v_layer/b"]).max())
+        np.testing.assert_allclose(v["bh"], g[f"{name}/h_layer/b"], rtol=0, atol=TOL_G * np.abs(g[f"{name}/h_layer/b"]).max())
+        np.testing.assert_allclose(v["wt"], g[f"{name}/t_layer/W"], rtol=0, atol=TOL_G * np.abs(g[f"{name}/t_layer/W"]).max())
+        np.testing.assert_allclose(v["coeff_s"], g[f"{name}/coeff_scale"].reshape(-1), rtol=0,
+                                   atol=TOL_G * np.abs(g[f"{name}/coeff_scale"]).max())
+        np.testing.assert_allclose(v["coeff_q"], g[f"{name}/coeff_transformation"].reshape(-1), rtol=0,
+                                   atol=TOL_G * np.abs(g[f"{name}/coeff_transformation"]).max())
+        # big matrices: sum |.| and sum of squares of each reference-layout block, and its first row
+        blocks = {"v_layer/W": v["w1_t"][:, :D].T, "x_layer/W": v["w1_t"][:, D:].T, "h_layer/W": v["wh_t"].T,
+                  "scale_layer/W": v["whd_t"][0].T, "translation_layer/W": v["whd_t"][1].T,
+                  "transformation_layer/W": v["whd_t"][2].T}
+        for k, blk in blocks.items():
+            st = g[f"{name}/{k}/stats"]
+            assert np.abs(blk).sum() == pytest.approx(st[1], rel=TOL_G), (name, k)
+            assert (blk * blk).sum() == pytest.approx(st[2], rel=2 * TOL_G), (name, k)
+            r0 = g[f"{name}/{k}/row0"]
+            np.testing.assert_allclose(blk[0], r0, rtol=0, atol=TOL_G * max(np.abs(r0).max(), np.sqrt(st[2] / blk.size)))
+
+
+def test_toy_target_gradients_match_committed_fixture():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_mog.npz"))
+    import l2hmc_amd as la
+    from l2hmc_amd.dynamics_trainer import DynamicsTrainer
+    N, nh = int(g["trajectory_length"]), int(g["num_nodes"])
+    xp, vp = H.mlp_weights(2, nh, seed=106, regime=str(g["regime"]))
+    tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=N, eps=float(g["eps"]),
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=nh))
+    dyn.set_masks(g["masks"])
+    dyn.XNet.load_state(xp)
+    dyn.VNet.load_state(vp)
+    tr = DynamicsTrainer(dyn, scale=float(g["scale"]))
+    dx = tuple(g[f"draws_x/{i}"] for i in range(4))
+    dz = tuple(g[f"draws_z/{i}"] for i in range(4))
+    loss, x_out, px = tr.calc_loss_and_grads(g["x"], z=g["z"], draws_x=dx, draws_z=dz)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-4)
+    assert H.relerr(tr.last_proposals.cpu().numpy(), np.concatenate([g["Lx"], g["Lz"]])) < 1e-5
+    gv = tr.grad_views()
+    assert float(gv["alpha"][0]) == pytest.approx(float(g["grad_alpha"]), rel=TOL_G)
+    for name in ("xnet", "vnet"):
+        v = {k: t.cpu().numpy().astype(np.float64) for k, t in gv[name].items()}
+        ref = {"w1_t": np.concatenate([g[f"{name}/embed_1/W"], g[f"{name}/embed_2/W"]], axis=0).T,
+               "wt": g[f"{name}/embed_3/W"], "b1": g[f"{name}/embed_1/b"], "wh_t": g[f"{name}/linear_1/W"].T,
+               "bh": g[f"{name}/linear_1/b"],
+               "whd_t": np.stack([g[f"{name}/linear_s/W"].T, g[f"{name}/linear_t/W"].T, g[f"{name}/linear_f/W"].T]),
+               "coeff_s": g[f"{name}/scale_s"].reshape(-1), "coeff_q": g[f"{name}/scale_f"].reshape(-1)}
+        for k, want in ref.items():
+            np.testing.assert_allclose(v[k].reshape(want.shape), want, rtol=0, atol=TOL_G * np.abs(want).max(), err_msg=f"{name}.{k}")
