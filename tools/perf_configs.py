@@ -58,6 +58,16 @@ def small(name, target, B, N, H):
     print(f"{name:46s} {dt*1e3:10.3f} ms/propose     useful {B*N/dt/1e6:8.3f} M chain-LF/s", flush=True)
 
 
+def small_train(name, target, B, N, H):
+    from l2hmc_amd.dynamics_trainer import DynamicsTrainer
+    dyn = la.Dynamics(2, target.get_energy_function(), trajectory_length=N, eps=0.1,
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=H))
+    tr = DynamicsTrainer(dyn, lr_init=1e-3)
+    x = torch.randn(B, 2, device="cuda")
+    dt = timeit(lambda: tr.train_step(x), warm=3, iters=20)
+    print(f"{name:46s} {dt*1e3:10.3f} ms/train step  ({2*B} chains: forward + loss + reverse pass + Adam)", flush=True)
+
+
 def u1_roofline():
     from l2hmc_amd import _lib
     for L, rows in ((8, 1 << 21), (16, 1 << 19), (32, 1 << 17)):
@@ -90,6 +100,8 @@ def main():
           la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]])), 128, 5, 10)
     small("cfg2 MoG 2-D, B=4096, 10 LF, H=50",
           la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5]), 4096, 10, 50)
+    small_train("cfg2 MoG training step, B=4096, 10 LF, H=50",
+                la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5]), 4096, 10, 50)
     gauge("cfg3 U(1) 8x8 generic, B=2048, 10 LF (fused)", 8, 2048, 10, 0.25, 2.0, 'generic', iters=10)
     gauge("cfg3 U(1) 8x8 generic, B=2048, 10 LF (layered)", 8, 2048, 10, 0.25, 2.0, 'generic', iters=10, fused=False)
     gauge("cfg3 U(1) 8x8 conv3D,  B=2048, 10 LF", 8, 2048, 10, 0.25, 2.0, 'conv3D', iters=10)

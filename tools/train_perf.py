@@ -16,10 +16,11 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    arch = sys.argv[4] if len(sys.argv) > 4 else 'generic'
     L = 8
     np.random.seed(42)
     lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=B, rand=True)
-    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.25, hmc=False, network_arch='generic', num_steps=N,
+    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.25, hmc=False, network_arch=arch, num_steps=N,
                            eps_trainable=True)
     tr = GaugeTrainer(dyn, lr_init=1e-4)
     x = torch.as_tensor(lat.samples.reshape(B, -1), dtype=torch.float32, device="cuda")
@@ -32,7 +33,7 @@ def main():
             fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
-        print(f"{name}: {dt*1e3:.2f} ms  ({2*B*N/dt/1e6:.2f} M chain-LF/s through forward+backward, rows={2*B})", flush=True)
+        print(f"[{arch}] {name}: {dt*1e3:.2f} ms  ({2*B*N/dt/1e6:.2f} M chain-LF/s through forward+backward, rows={2*B})", flush=True)
     print("ws GB", la._lib.lib().l2hmc_gauge_train_ws_bytes(__import__('ctypes').byref(dyn._plan()), 2 * B) / 1e9)
 
 
