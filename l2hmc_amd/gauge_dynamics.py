@@ -33,6 +33,7 @@ class GaugeDynamics:
         self.eps_trainable, self.data_format = True, 'channels_last'
         self.both_directions = True      # integrate fwd AND bwd like :211-218; False = selected only
         self.fused = True                # whole-trajectory kernel where the shape has one
+        self.check_numerics = False      # True: raise on a non-finite trajectory like tf.check_numerics (:26-28)
         for key, val in kwargs.items():
             if key != 'eps':             # :73-75
                 setattr(self, key, val)
@@ -185,6 +186,10 @@ class GaugeDynamics:
             _lib.dev_ptr(v0b, name="momentum_b"), _lib.dev_ptr(coin, name="coin"), _lib.dev_ptr(u, name="u"),
             B, both, x_prop.data_ptr(), v_prop.data_ptr(), p.data_ptr(), x_out.data_ptr(), ws, nb,
             _lib.stream_ptr()))
+        if self.check_numerics and not bool(torch.isfinite(x_prop).all() & torch.isfinite(v_prop).all()):
+            # the reference wraps every exp of the sub-updates in tf.check_numerics and aborts the step;
+            # the kernels propagate NaN / inf instead, and this opt-in check (one host sync) reports it
+            raise FloatingPointError("check_numerics: non-finite value in the proposed configuration")
         return x_prop, v_prop, p, x_out
 
     def transition_kernel(self, position, beta, forward=True, momentum=None, return_logdet=False):

@@ -57,6 +57,7 @@ class GaugeTrainer:
         self._eps_dev = torch.tensor([float(dyn.eps)], dtype=torch.float32, device=dev)
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = _lib.Workspace()
+        self.broadcast_weights()
         self._grad_structs, self._conv_grad_structs = [], []
         off = 0
         for net, (flat, views, offsets) in zip(self._nets, flats):
@@ -65,6 +66,19 @@ class GaugeTrainer:
             conv = [k for k in offsets if k not in net.SEGMENTS]
             self._conv_grad_structs.append(_lib.Conv3DGrads(**{k: at(k) for k in conv}) if conv else None)
             off += flat.numel()
+
+    def broadcast_weights(self, src=0):
+        """hvd.BroadcastGlobalVariablesHook(0) (gauge_model.py:1008): every rank starts from rank `src`'s
+        weights, step size and masks -- one broadcast per flat buffer."""
+        if self.dist is None:
+            return
+        dyn = self.dynamics
+        for net in self._nets:
+            self.dist.broadcast(net.flat_params()[0], src=src)
+            net.refresh_packed()
+        self.dist.broadcast(self._eps_dev, src=src)
+        dyn.eps = self._eps_dev.detach().cpu().reshape(())
+        self.dist.broadcast(dyn.mask, src=src)
 
     # ---- views ----------------------------------------------------------------
     def grad_views(self):

@@ -142,3 +142,66 @@ def autocorr_new(y, c=5.0):
     f = autocorr_func_1d(np.asarray(y, dtype=np.float64).T).mean(axis=1)
     taus = 2. * np.cumsum(f) - 1.
     return taus[auto_window(taus, c)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Run statistics (l2hmc/gauge_model.py:1473-1531 `calc_observables_stats`) and block-jackknife errors
+# (l2hmc/utils/data_utils.py:66-143); plain NumPy, no scikit-learn / scipy dependency.
+# ---------------------------------------------------------------------------------------------
+def sem(a):
+    """scipy.stats.sem along axis 0: sample standard deviation (ddof = 1) / sqrt(n)."""
+    a = np.asarray(a, dtype=np.float64)
+    return a.std(axis=0, ddof=1) / np.sqrt(a.shape[0])
+
+
+def block_resampling(data, num_blocks):
+    """data_utils.py:66-84: the `num_blocks` leave-one-block-out resamples of `data` along axis 0.  Blocks are the
+    contiguous folds of sklearn.model_selection.KFold without shuffling: the first n % k folds hold n // k + 1
+    samples, the rest n // k."""
+    data = np.asarray(data)
+    n = data.shape[0]
+    if n < 1:
+        raise ValueError("Data must have at least one sample.")
+    if num_blocks < 1:
+        raise ValueError("Number of resampled blocks must be greater than or equal to 1.")
+    if n < num_blocks:
+        num_blocks = max(2, n)
+    if num_blocks > n:
+        raise ValueError(f"Cannot have number of splits n_splits={num_blocks} greater than the number of samples: {n}.")
+    sizes = np.full(num_blocks, n // num_blocks)
+    sizes[: n % num_blocks] += 1
+    out, start = [], 0
+    for sz in sizes:
+        out.append(np.concatenate([data[:start], data[start + sz:]]))
+        start += sz
+    return out
+
+
+def jackknife_err(y_i, y_full, num_blocks):
+    """data_utils.py:106-116: sqrt( sum (y_i - y_full)^2 / (num_blocks - 1) * num_blocks )  (as written)."""
+    y_i, y_full = np.asarray(y_i), np.asarray(y_full)
+    return np.sqrt(np.sum((y_i - y_full) ** 2) / (num_blocks - 1) * num_blocks)
+
+
+def calc_avg_vals_errors(data, num_blocks=100):
+    """data_utils.py:119-143 -> (mean, block-jackknife error)."""
+    arr = np.asarray(data)
+    avg = np.mean(arr)
+    rs = [np.mean(b) for b in block_resampling(arr, num_blocks)]
+    return avg, jackknife_err(rs, avg, num_blocks)
+
+
+def calc_observables_stats(actions, plaqs, charges, therm_frac=10):
+    """gauge_model.py:1473-1531 on [steps, chains] histories (what GaugeSampler.run returns): drop the first
+    steps // therm_frac steps, per-chain means and standard errors of action, plaquette, topological charge and
+    susceptibility Q^2, and the charge histogram.  As in the reference the susceptibility series is NOT
+    thermalisation-trimmed (it is squared before the cut)."""
+    actions, plaqs = np.asarray(actions, dtype=np.float64), np.asarray(plaqs, dtype=np.float64)
+    charges = np.asarray(np.asarray(charges), dtype=int)           # np.array(..., dtype=int) truncates like the reference
+    suscept = charges ** 2
+    therm = actions.shape[0] // therm_frac
+    actions, plaqs, charges = actions[therm:], plaqs[therm:], charges[therm:]
+    vals, counts = np.unique(charges, return_counts=True)
+    probs = {int(v): float(c) / counts.sum() for v, c in zip(vals, counts)}
+    return ((actions.mean(axis=0), sem(actions)), (plaqs.mean(axis=0), sem(plaqs)),
+            (charges.mean(axis=0), sem(charges)), (suscept.mean(axis=0), sem(suscept)), probs)

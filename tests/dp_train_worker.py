@@ -21,6 +21,10 @@ def main():
     tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, B, "mild")
     lo, hi = shard_bounds(B, world, rank)
     from l2hmc_amd.gauge_trainer import GaugeTrainer
+    if rank == 1:      # a replica that starts out of sync: the trainer's initial broadcast must repair it
+        for net in (tr.dynamics.position_fn, tr.dynamics.momentum_fn):
+            net.flat_params()[0].mul_(1.5)
+        tr.dynamics.eps = tr.dynamics.eps * 2
     tr = GaugeTrainer(tr.dynamics, dist=dist)
     loss, *_ = tr.calc_loss_and_grads(x[lo:hi], 2.5, z=z[lo:hi], draws_x=tuple(a[lo:hi] for a in dx),
                                       draws_z=tuple(a[lo:hi] for a in dz))

@@ -659,3 +659,23 @@ def test_full_size_properties_cfg3(la):
     out = dyn(x, beta)
     same = (out[3] == x).all(1) | (out[3] == out[0]).all(1)
     assert bool(same.all())
+
+
+def test_check_numerics_opt_in(la):
+    """gauge_dynamics.py:26-28: the reference aborts a step whose exp overflows; here NaN/inf propagate by default
+    (non-finite accept probability -> 0, :609) and `check_numerics=True` turns that into an exception."""
+    T = X = 4
+    xp, vp = H.gauge_weights(T, X, regime="stress")
+    for k in ("scale_layer/b",):
+        xp[k] = xp[k] + 400.0          # exp(eps * S) overflows fp32 in the position update
+    xp["coeff_scale"] = xp["coeff_scale"] + 6.0
+    orc = H.gauge_oracle(T, X, 2, 0.3, xp, vp)
+    dyn = H.gauge_hip(T, X, 2, 0.3, xp, vp, orc.mask, 6)
+    x, v0f, v0b, coin, u = H.gauge_inputs(6, 32)
+    x_prop, v_prop, p, x_out = dyn.apply_transition(x, 2.0, v0f, v0b, coin, u)
+    assert not torch.isfinite(x_prop).all()
+    assert torch.isfinite(p).all() and float(p.max()) == 0.0           # rejected, chains keep their state
+    assert torch.equal(x_out, torch.as_tensor(x, dtype=torch.float32, device=x_out.device))
+    dyn.check_numerics = True
+    with pytest.raises(FloatingPointError):
+        dyn.apply_transition(x, 2.0, v0f, v0b, coin, u)

@@ -234,3 +234,42 @@ def test_integrated_time_known_answer_and_errors():
     w = _ar1(4000, 6, 0.5).T
     assert stats.autocorr_new(w) == pytest.approx(3.0, rel=0.2)
     assert stats.autocorr_gw2010(w) > 0
+
+
+def test_block_jackknife_and_run_statistics():
+    from l2hmc_amd import stats
+    rng = np.random.default_rng(2)
+    data = rng.standard_normal(1003)
+    blocks = stats.block_resampling(data, 100)
+    assert len(blocks) == 100 and all(len(b) in (1003 - 11, 1003 - 10) for b in blocks)
+    try:                                    # the reference builds the blocks with sklearn's KFold
+        from sklearn.model_selection import KFold
+        for (tr, _), b in zip(KFold(n_splits=100).split(data), blocks):
+            np.testing.assert_array_equal(data[tr], b)
+    except ImportError:
+        pass
+    avg, err = stats.calc_avg_vals_errors(data, 100)
+    assert avg == pytest.approx(data.mean())
+    # delete-a-block jackknife of the mean ~ standard error (the reference's formula carries an extra factor
+    # num_blocks / (num_blocks - 1) ... times num_blocks; restated as written)
+    rs = np.array([b.mean() for b in blocks])
+    assert err == pytest.approx(np.sqrt(np.sum((rs - avg) ** 2) / 99 * 100))
+    assert len(stats.block_resampling(np.arange(5), 100)) == 5       # fewer samples than blocks
+    with pytest.raises(ValueError):
+        stats.block_resampling(np.array([]), 3)
+    # run statistics on [steps, chains] histories
+    steps, chains = 50, 4
+    actions, plaqs = rng.uniform(10, 20, (steps, chains)), rng.uniform(0, 1, (steps, chains))
+    charges = rng.integers(-2, 3, (steps, chains)).astype(np.float64) + 0.4      # truncation to int as np.array(dtype=int)
+    (am, ae), (pm, pe), (qm, qe), (sm, se), probs = stats.calc_observables_stats(actions, plaqs, charges, therm_frac=10)
+    np.testing.assert_allclose(am, actions[5:].mean(0))
+    np.testing.assert_allclose(pe, plaqs[5:].std(0, ddof=1) / np.sqrt(45))
+    qi = charges.astype(int)
+    np.testing.assert_allclose(qm, qi[5:].mean(0))
+    np.testing.assert_allclose(sm, (qi ** 2).mean(0))                  # not trimmed, as the reference
+    assert sum(probs.values()) == pytest.approx(1.0) and set(probs) <= {-1, 0, 1, 2}
+    try:
+        from scipy.stats import sem as scipy_sem
+        np.testing.assert_allclose(stats.sem(actions), scipy_sem(actions))
+    except ImportError:
+        pass
