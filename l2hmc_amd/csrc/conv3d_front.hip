@@ -14,16 +14,21 @@
 // This stage is <20 % of the network's FLOPs and VALU-bound; filters are read with
 // the channel index on the lane (conflict-free), inputs as LDS broadcasts.
 #include "stq_dense.h"
+#include <stdlib.h>
 
 namespace l2hmc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kConvThreads = 256;
 
+// FT / LT: compile-time filter count and (square) lattice extent, 0 = take them from the arguments.  The index
+// arithmetic of every phase divides by F, X/2, ...: with constants these are shifts, with run-time values
+// ~30-instruction sequences that dominate the kernel.
+template <int FT, int LT>
 __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;                   // 0: first input, 1: second input
-  const int T = p.T, X = p.X, F = p.F, F2 = 2 * p.F;
+  const int T = LT ? LT : p.T, X = LT ? LT : p.X, F = FT ? FT : p.F, F2 = 2 * F;
   const int D = 2 * T * X;
   const int TP = T + 2, XP = X + 2;               // conv1 halo (pad 1 / 1)
   const int T2 = T / 2, X2 = X / 2, T2P = T2 + 1, X2P = X2 + 1;   // conv2 pad (0 / 1)
@@ -146,20 +151,29 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
                 "conv3d front-end: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
-  a.cpw = per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
+  a.cpw = per_chain >= 1024 ? 1 : (1024 / per_chain > 8 ? 8 : 1024 / per_chain);   // amortise filter loads / barriers
   if (a.ldi == 0) a.ldi = 2 * a.T * a.X;
   const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
                                       (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
+  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<8, 8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<16, 16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<0, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
-  hipLaunchKernelGGL(conv3d_front_kernel, grid, dim3(kConvThreads), lds, stream, a);
+  if (a.F == 8 && a.T == 8 && a.X == 8)
+    hipLaunchKernelGGL((conv3d_front_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
+  else if (a.F == 16 && a.T == 16 && a.X == 16)
+    hipLaunchKernelGGL((conv3d_front_kernel<16, 16>), grid, dim3(kConvThreads), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv3d_front_kernel<0, 0>), grid, dim3(kConvThreads), lds, stream, a);
   L2HMC_CHECK_LAUNCH("conv3d_front");
   return L2HMC_OK;
 }
@@ -177,10 +191,11 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
 // ([workgroup][input][18F | F | 16F^2 (Keras layout, dd = 1 rows stay 0) | 2F]); the same workgroup
 // sees the same chains in every call, and the slots are summed in order afterwards.
 // =====================================================================================
+template <int FT, int LT>
 __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;
-  const int T = p.T, X = p.X, F = p.F, F2 = 2 * p.F;
+  const int T = LT ? LT : p.T, X = LT ? LT : p.X, F = FT ? FT : p.F, F2 = 2 * F;
   const int D = 2 * T * X;
   const int TP = T + 2, XP = X + 2;
   const int T2 = T / 2, X2 = X / 2, T2P = T2 + 1, X2P = X2 + 1;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
+  if (p.dbg == 1) return;
   // ---- phase 2: conv2 + pool2 winners; gradient of the surviving features
   const int n2 = nrow * T4 * X4 * F2;
   for (int idx = tid; idx < n2; idx += kConvThreads) {
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
+  if (p.dbg == 2) return;
   // ---- phase 3: gradient of the pooled conv1 map, gated by its own relu / winner
   for (int idx = tid; idx < n1; idx += kConvThreads) {
     const int ch = idx % F;
@@ -321,6 +338,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
+  if (p.dbg == 3) return;
   // ---- phase 4: gradient of the raw input (zero padding: no periodic wrap, as the forward)
   for (int i = tid; i < nrow * D; i += kConvThreads) {
     const int c = i / D, e = i - c * D;
@@ -349,14 +367,19 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     p.din[(row0 + c) * p.ldd + which * D + e] = gsum;
   }
 
-  // ---- phase 5: filter / bias gradients, one owner thread per entry
-  const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
-  float* part = p.part + ((size_t)blockIdx.x * 2 + which) * psize;
-  for (int ent = tid; ent < 18 * F; ent += kConvThreads) {
-    const int f = ent % F, dd = (ent / F) & 1, tap = ent / (2 * F);
-    const int di = tap / 3, dj = tap - di * 3;
+  if (p.dbg == 4) return;
+  // ---- phase 5: filter / bias gradients.  Work items are (chain, entry) pairs (every thread busy); each writes
+  // its chain's contribution to LDS, then one owner thread per entry adds the chains in order and accumulates
+  // into the workgroup's slot.
+  __syncthreads();
+  const int nent = 18 * F + F + 4 * F * F2 + F2;        // compact: w1 | b1 | w2 (dd = 0 slice) | b2
+  float* pw = reinterpret_cast<float*>(arg2 + ((cpw * T4 * X4 * F2 + 15) & ~15));   // [cpw][nent]
+  for (int item = tid; item < nrow * nent; item += kConvThreads) {
+    const int c = item / nent, ent = item - c * nent;
     float s = 0.f;
-    for (int c = 0; c < nrow; ++c)
+    if (ent < 18 * F) {
+      const int f = ent % F, dd = (ent / F) & 1, tap = ent / (2 * F);
+      const int di = tap / 3, dj = tap - di * 3;
       for (int I = 0; I < T2; ++I)
         for (int J = 0; J < X2; ++J) {
           const int cell = ((c * T2 + I) * X2 + J) * F + f;
@@ -367,19 +390,13 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
           const float xv = depth == 0 ? px[dd] : (dd == 0 ? px[1] : 0.f);
           s += dpre1[cell] * xv;
         }
-    part[ent] += s;
-  }
-  for (int f = tid; f < F; f += kConvThreads) {
-    float s = 0.f;
-    for (int cell = 0; cell < nrow * T2 * X2; ++cell) s += dpre1[cell * F + f];
-    part[18 * F + f] += s;
-  }
-  float* pw2 = part + 18 * F + F;
-  for (int ent = tid; ent < 4 * F * F2; ent += kConvThreads) {
-    const int g = ent % F2, ch = (ent / F2) % F, tap = ent / (F2 * F);
-    const int di = tap >> 1, dj = tap & 1;
-    float s = 0.f;
-    for (int c = 0; c < nrow; ++c)
+    } else if (ent < 19 * F) {
+      const int f = ent - 18 * F;
+      for (int cell = c * T2 * X2; cell < (c + 1) * T2 * X2; ++cell) s += dpre1[cell * F + f];
+    } else if (ent < 19 * F + 4 * F * F2) {
+      const int e2 = ent - 19 * F;
+      const int g = e2 % F2, ch = (e2 / F2) % F, tap = e2 / (F2 * F);
+      const int di = tap >> 1, dj = tap & 1;
       for (int I2 = 0; I2 < T4; ++I2)
         for (int J2 = 0; J2 < X4; ++J2) {
           const int cell = ((c * T4 + I2) * X4 + J2) * F2 + g;
@@ -388,40 +405,75 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
           const int i2 = 2 * I2 + (code >> 1), j2 = 2 * J2 + (code & 1);
           s += d2[cell] * p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
         }
-    pw2[((size_t)(tap * 2 + 0) * F + ch) * F2 + g] += s;
+    } else {
+      const int g = ent - 19 * F - 4 * F * F2;
+      for (int cell = c * T4 * X4; cell < (c + 1) * T4 * X4; ++cell) s += d2[cell * F2 + g];
+    }
+    pw[item] = s;
   }
-  float* pb2 = pw2 + (size_t)16 * F * F;
-  for (int g = tid; g < F2; g += kConvThreads) {
+  __syncthreads();
+  const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
+  float* part = p.part + ((size_t)blockIdx.x * 2 + which) * psize;
+  for (int ent = tid; ent < nent; ent += kConvThreads) {
     float s = 0.f;
-    for (int cell = 0; cell < nrow * T4 * X4; ++cell) s += d2[cell * F2 + g];
-    pb2[g] += s;
+    for (int c = 0; c < nrow; ++c) s += pw[c * nent + ent];
+    size_t dst;                                          // slot layout: Keras kernels, dd = 1 rows of w2 stay 0
+    if (ent < 19 * F) dst = ent;
+    else if (ent < 19 * F + 4 * F * F2) {
+      const int e2 = ent - 19 * F;
+      const int g = e2 % F2, ch = (e2 / F2) % F, tap = e2 / (F2 * F);
+      dst = (size_t)19 * F + ((size_t)(tap * 2 + 0) * F + ch) * F2 + g;
+    } else dst = (size_t)19 * F + (size_t)16 * F * F + (ent - 19 * F - 4 * F * F2);
+    part[dst] += s;
   }
 }
 
 size_t conv3d_bwd_part_floats(int F) { return (size_t)18 * F + F + (size_t)16 * F * F + 2 * F; }
+// chains per workgroup of the BACKWARD kernel: enough work items (~2048 pooled conv1 cells) to amortise the
+// filter loads, the barriers and the read-modify-write of the workgroup's gradient slot
 int conv3d_cpw(int T, int X, int F) {
   const int per_chain = (T / 2) * (X / 2) * F;
-  return per_chain >= kConvThreads ? 1 : kConvThreads / per_chain;
+  static const int override_ = [] {
+    const char* e = getenv("L2HMC_CONV_BWD_CPW");
+    return e ? atoi(e) : 0;
+  }();
+  if (override_ > 0) return override_;
+  const int c = 512 / per_chain;
+  return c < 1 ? 1 : (c > 16 ? 16 : c);
 }
 
 int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
                 "conv3d front-end backward: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   a.cpw = conv3d_cpw(a.T, a.X, a.F);
+  {
+    static const int dbg = [] { const char* e = getenv("L2HMC_CONV_BWD_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+  }
   const size_t cells1 = (size_t)a.cpw * (a.T / 2) * (a.X / 2) * a.F, cells2 = (size_t)a.cpw * (a.T / 4) * (a.X / 4) * 2 * a.F;
   const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
-                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F + cells1 + cells2) +
-                     align_up(cells1 + cells2, 16);
+                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F + cells1 + cells2 +
+                                      (size_t)a.cpw * (19 * a.F + 8 * a.F * a.F + 2 * a.F)) +
+                     align_up(cells1, 1) + align_up(cells2, 16) + 16;
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
+  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<8, 8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<16, 16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<0, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
-  hipLaunchKernelGGL(conv3d_front_bwd_kernel, grid, dim3(kConvThreads), lds, stream, a);
+  if (a.F == 8 && a.T == 8 && a.X == 8)
+    hipLaunchKernelGGL((conv3d_front_bwd_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
+  else if (a.F == 16 && a.T == 16 && a.X == 16)
+    hipLaunchKernelGGL((conv3d_front_bwd_kernel<16, 16>), grid, dim3(kConvThreads), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv3d_front_bwd_kernel<0, 0>), grid, dim3(kConvThreads), lds, stream, a);
   L2HMC_CHECK_LAUNCH("conv3d_front_bwd");
   return L2HMC_OK;
 }

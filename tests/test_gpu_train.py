@@ -456,3 +456,36 @@ def test_toy_target_gradients_match_committed_fixture():
                "coeff_s": g[f"{name}/scale_s"].reshape(-1), "coeff_q": g[f"{name}/scale_f"].reshape(-1)}
         for k, want in ref.items():
             np.testing.assert_allclose(v[k].reshape(want.shape), want, rtol=0, atol=TOL_G * np.abs(want).max(), err_msg=f"{name}.{k}")
+
+
+def test_conv3d_gradients_generic_filter_count():
+    """num_filters != lattice extent runs the run-time-shaped instantiation of the conv kernels (forward and
+    backward); the specialised ones (F = L = 8 / 16) are covered by the tests above."""
+    import l2hmc_amd as la
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    from oracle import nets as onets
+    T = X = 8
+    D, F, N, eps, B = 128, 4, 2, 0.1, 7
+    rng = np.random.default_rng(106)
+    kw = H.REGIMES["mild"]
+    xp = onets.init_conv3d_net(rng, T, D, 2 * D, F, 2., **kw)
+    vp = onets.init_conv3d_net(rng, T, D, 2 * D, F, 1., **kw)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp, arch='conv3D')
+    dyn = H.gauge_hip(T, X, N, eps, H.conv_weights(T, X, regime="mild")[0], H.conv_weights(T, X, regime="mild")[1],
+                      orc.mask, B, arch='conv3D')
+    common = dict(_input_shape=(B, T, X, 2), links_shape=(T, X, 2), x_dim=D, spatial_size=X, num_hidden=2 * D,
+                  num_filters=F, filter_sizes=[(3, 3, 2), (2, 2, 2)], data_format='channels_last')
+    dyn.position_fn = la.ConvNet3D('XNet', factor=2., name_scope='position', **common)
+    dyn.momentum_fn = la.ConvNet3D('VNet', factor=1., name_scope='momentum', **common)
+    dyn.position_fn.load_state(xp)
+    dyn.momentum_fn.load_state(vp)
+    tr = GaugeTrainer(dyn)
+    tm = TorchGaugeModel(T, X, N, eps, orc.mask, xp, vp, arch='conv3D')
+    r2 = np.random.default_rng(7)
+    x, z = r2.uniform(0, 2 * np.pi, (B, D)), r2.standard_normal((B, D))
+    mk = lambda: (r2.standard_normal((B, D)), r2.standard_normal((B, D)), r2.uniform(size=B), r2.uniform(size=B))  # noqa: E731
+    dx, dz = mk(), mk()
+    loss, *_ = tr.calc_loss_and_grads(x, 2.5, z=z, draws_x=dx, draws_z=dz)
+    want, _ = _ref_grads(tm, x, z, dx, dz, 2.5, 'cos_diff')
+    assert abs(float(loss) - want) <= 2e-4 * max(1., abs(want))
+    _compare(tr, tm)
