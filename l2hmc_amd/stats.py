@@ -70,7 +70,8 @@ def autocorr_func_1d(x):
     if not hasattr(x, "shape") or len(x.shape) == 0:
         x = np.atleast_1d(x)
     acf = _acf_batched(x, 2 * next_pow_two(x.shape[0]))
-    return acf / acf[0]
+    with np.errstate(invalid='ignore', divide='ignore'):      # a constant series gives 0 / 0 = nan, as in the reference
+        return acf / acf[0]
 
 
 def autocorr_fast(X, kappa=500):
