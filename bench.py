@@ -251,6 +251,37 @@ def main():
                         "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
                 "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
                 "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss)}
+            if world == 1 and not args.no_cpu_baseline:
+                # the secondary metric with TRAINED networks: a short training run (same shape), then ESS/sec of
+                # the sampler with the estimator used above (untrained networks barely move a chain)
+                try:
+                    xt = x
+                    for i in range(250):
+                        _, xo, _, _ = tr.train_step(xt, BETA)
+                        xt = sampler.wrap(xo)
+                    tsm = GaugeSampler(tdyn)
+                    for _ in range(20):
+                        xt = tsm.step(xt, BETA)[0]
+                    torch.cuda.synchronize()
+                    te0 = time.perf_counter()
+                    hist2 = []
+                    for _ in range(64):
+                        xt = tsm.step(xt, BETA)[0]
+                        hist2.append(xt)
+                    tsm.stats.wait()
+                    torch.cuda.synchronize()
+                    ted = time.perf_counter() - te0
+                    X2 = torch.stack(hist2).cpu().numpy()
+                    f2 = np.concatenate([np.cos(X2), np.sin(X2)], axis=2)
+                    f2 = f2 - f2.mean(axis=(0, 1), keepdims=True)
+                    A2 = chain_stats.acl_spectrum(f2, 1.0)
+                    ess2 = float(chain_stats.ESS(A2 / A2[0]))
+                    out["config"]["after_260_train_steps"] = {
+                        "mean_accept_prob": tsm.stats.mean_accept(), "eps": float(tdyn.eps),
+                        "ess_per_mcmc_step": ess2, "ess_per_sec_whole_job": ess2 * BATCH * 64 / ted,
+                        "ms_per_mcmc_step": 1e3 * ted / 64}
+                except Exception as e:                # noqa: BLE001
+                    out["config"]["after_260_train_steps"] = {"error": repr(e)}
         else:
             out["config"]["train_step"] = {"error": err or "another rank failed"}
 
