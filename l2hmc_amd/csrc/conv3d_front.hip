@@ -14,7 +14,6 @@
 // This stage is <20 % of the network's FLOPs and VALU-bound; filters are read with
 // the channel index on the lane (conflict-free), inputs as LDS broadcasts.
 #include "stq_dense.h"
-#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -273,7 +272,6 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
-  if (p.dbg == 1) return;
   // ---- phase 2: conv2 + pool2 winners; gradient of the surviving features
   const int n2 = nrow * T4 * X4 * F2;
   for (int idx = tid; idx < n2; idx += kConvThreads) {
@@ -310,7 +308,6 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
-  if (p.dbg == 2) return;
   // ---- phase 3: gradient of the pooled conv1 map, gated by its own relu / winner
   for (int idx = tid; idx < n1; idx += kConvThreads) {
     const int ch = idx % F;
@@ -338,7 +335,6 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
-  if (p.dbg == 3) return;
   // ---- phase 4: gradient of the raw input (zero padding: no periodic wrap, as the forward)
   for (int i = tid; i < nrow * D; i += kConvThreads) {
     const int c = i / D, e = i - c * D;
@@ -367,7 +363,6 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     p.din[(row0 + c) * p.ldd + which * D + e] = gsum;
   }
 
-  if (p.dbg == 4) return;
   // ---- phase 5: filter / bias gradients.  Work items are (chain, entry) pairs (every thread busy); each writes
   // its chain's contribution to LDS, then one owner thread per entry adds the chains in order and accumulates
   // into the workgroup's slot.
@@ -433,11 +428,6 @@ size_t conv3d_bwd_part_floats(int F) { return (size_t)18 * F + F + (size_t)16 * 
 // filter loads, the barriers and the read-modify-write of the workgroup's gradient slot
 int conv3d_cpw(int T, int X, int F) {
   const int per_chain = (T / 2) * (X / 2) * F;
-  static const int override_ = [] {
-    const char* e = getenv("L2HMC_CONV_BWD_CPW");
-    return e ? atoi(e) : 0;
-  }();
-  if (override_ > 0) return override_;
   const int c = 512 / per_chain;
   return c < 1 ? 1 : (c > 16 ? 16 : c);
 }
@@ -446,10 +436,6 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
                 "conv3d front-end backward: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   a.cpw = conv3d_cpw(a.T, a.X, a.F);
-  {
-    static const int dbg = [] { const char* e = getenv("L2HMC_CONV_BWD_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
-  }
   const size_t cells1 = (size_t)a.cpw * (a.T / 2) * (a.X / 2) * a.F, cells2 = (size_t)a.cpw * (a.T / 4) * (a.X / 4) * 2 * a.F;
   const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +

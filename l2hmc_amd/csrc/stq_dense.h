@@ -97,7 +97,6 @@ struct ConvBwdArgs {
   float* part;                           // [workgroups][2][conv3d_bwd_part_floats(F)], +=
   int64_t rows;
   int cpw;
-  int dbg;                               // timing experiments only
 };
 size_t conv3d_bwd_part_floats(int F);
 int conv3d_cpw(int T, int X, int F);

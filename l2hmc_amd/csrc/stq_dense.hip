@@ -23,7 +23,6 @@
 // 16-row ones).  Tile ids are remapped so tiles sharing activation rows land on
 // one XCD (shared L2).
 #include "stq_dense.h"
-#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -414,14 +413,6 @@ int dense_net_supported(const l2hmc_dense_net* n) {
          (n->H % BK) == 0;
 }
 
-static bool narrow_tiles() {
-  static const int mode = [] {
-    const char* e = getenv("L2HMC_GEMM_NARROW");
-    return e ? atoi(e) : 1;
-  }();
-  return mode != 0;
-}
-
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.K % BK == 0 && a.K1 % BK == 0 && a.K1 <= a.K, "gemm: K=%d K1=%d must be multiples of %d",
                 a.K, a.K1, BK);
@@ -449,7 +440,7 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     a.mtiles = (int)ceil_div(a.rows, big ? 128 : 64);
     const dim3 grid(a.mtiles * a.ntiles);
     const bool deep3 = !big && (a.K % 64 == 0) && a.mtiles * a.ntiles <= 256;
-    if (deep3 && narrow_tiles()) {
+    if (deep3) {
       a.ntiles = (int)ceil_div(a.N, 64);
       const dim3 g64(a.mtiles * a.ntiles);
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
@@ -457,9 +448,6 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     } else if (big) {
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<128, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<128, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
-    } else if (deep3) {
-      if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 64>), grid, dim3(kGemmThreads), 0, stream, a);
-      else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 64>), grid, dim3(kGemmThreads), 0, stream, a);
     } else {
       if (a.kind == 3) hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 32>), grid, dim3(kGemmThreads), 0, stream, a);
@@ -468,9 +456,8 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
     return L2HMC_OK;
   }
   prof_before(cls, stream);
-  // 64-deep k-tiles halve the number of barriers (K ranges must be multiples of 64); their 102 KB of LDS allow one
-  // workgroup per CU, so they are used when the grid has at most one workgroup per CU anyway -- larger grids
-  // keep 32-deep tiles and two co-resident workgroups that hide each other's stalls
+  // grids that cannot fill the chip with 64 x 128 tiles (<= 256 of them) run 64 x 64 tiles with 64-deep k-tiles:
+  // half the barriers, twice the workgroups, 70 KB of LDS each => two co-resident workgroups per CU
   const bool deep = (a.K % 64 == 0) && (a.K1 % 64 == 0) && ceil_div(a.rows, 64) * a.ntiles <= 256;
   if (t128 >= 512) {
     a.mtiles = (int)ceil_div(a.rows, 128);
@@ -480,16 +467,13 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   } else {
     a.mtiles = (int)ceil_div(a.rows, 64);
     const dim3 grid(a.mtiles * a.ntiles);
-    if (deep && narrow_tiles()) {
+    if (deep) {
       // 64 x 64 tiles: twice the workgroups, 70 KB of LDS each => two co-resident workgroups per CU with
       // independent barriers (two waves per SIMD) instead of one
       a.ntiles = (int)ceil_div(a.N, 64);
       const dim3 g64(a.mtiles * a.ntiles);
       if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 64, 64>), g64, dim3(kGemmThreads), 0, stream, a);
-    } else if (deep) {
-      if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 64>), grid, dim3(kGemmThreads), 0, stream, a);
-      else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 64>), grid, dim3(kGemmThreads), 0, stream, a);
     } else {
       if (first) hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 32>), grid, dim3(kGemmThreads), 0, stream, a);
       else hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 32>), grid, dim3(kGemmThreads), 0, stream, a);

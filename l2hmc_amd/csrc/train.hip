@@ -24,7 +24,6 @@
 //  * every reduction runs in a fixed order (no float atomics): results are reproducible.
 #include "stq_dense.h"
 #include <math.h>
-#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -704,20 +703,6 @@ struct TrainWs {
 
 static inline int64_t imax64(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
-static bool train_fused_forward() {
-  static const int mode = [] {
-    const char* e = getenv("L2HMC_TRAIN_FUSED");
-    return e ? atoi(e) : 1;
-  }();
-  return mode != 0;
-}
-static bool train_fused_backward() {
-  static const int mode = [] {
-    const char* e = getenv("L2HMC_TRAIN_FUSED_BWD");
-    return e ? atoi(e) : 1;
-  }();
-  return mode != 0;
-}
 static int64_t upd_blocks(int64_t rows) { return ceil_div(rows, kUpdRows); }
 static int tn_splits(int mt, int nt, int64_t R) {
   int s = (int)imax64(1, 512 / ((int64_t)mt * nt));
@@ -995,7 +980,7 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
   L2HMC_CHECK_LAUNCH("invert_mask");
   float* x = x_out;
   float* v = v_out;
-  if (train_fused_forward() && fused_train_supported(plan)) {
+  if (fused_train_supported(plan)) {
     // whole-trajectory kernel (fused_traj.hip) writing the same tape: one launch instead of ~6 per network call
     const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.gate};
     return launch_fused_trajectory(plan, beta, 0, N, x, v, dir, rows, x, v, sumlogdet, 0, p_accept, s, 0, 0, &tx, &tv);
@@ -1112,7 +1097,7 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     L2HMC_CHECK_LAUNCH("update_bwd");
     return call_backward_data(plan, net, t, call, rows, w, s);
   };
-  const bool fused_bwd = train_fused_forward() && train_fused_backward() && fused_train_supported(plan);
+  const bool fused_bwd = fused_train_supported(plan);     // the forward call took the same branch and left the relu masks
   int64_t ncoef = nblk;            // workgroups that wrote coefficient / step-size partials
   if (fused_bwd) {
     // one launch for the whole reverse data path (fused_train.hip)
