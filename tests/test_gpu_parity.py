@@ -680,3 +680,19 @@ def test_check_numerics_opt_in(la):
     dyn.check_numerics = True
     with pytest.raises(FloatingPointError):
         dyn.apply_transition(x, 2.0, v0f, v0b, coin, u)
+
+
+def test_c_abi_from_plain_c_host_program(tmp_path):
+    """The drop-in boundary is a C ABI: a C99 program compiled with gcc (no Python, no torch, no HIP compiler)
+    allocates device memory through the HIP runtime and drives the library (examples/c_abi_demo.c)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "l2hmc_amd")
+    cmd = ["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_abi_demo.c"),
+           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-L" + libdir, "-l:libl2hmc_hip.so",
+           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c_abi_demo OK" in out.stdout and "cold start: action 0.000000  avg_plaq 1.000000" in out.stdout
