@@ -31,16 +31,17 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "l2hmc_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(l2hmc_dense_net),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(l2hmc_dense_net),'
         ' sizeof(l2hmc_conv3d_front), sizeof(l2hmc_gauge_plan), sizeof(l2hmc_mog_target), sizeof(l2hmc_small_plan),'
         ' offsetof(l2hmc_dense_net, packed), offsetof(l2hmc_gauge_plan, masks), offsetof(l2hmc_gauge_plan, vfront),'
-        ' offsetof(l2hmc_small_plan, target)); return 0;}\n')
+        ' offsetof(l2hmc_small_plan, target), sizeof(l2hmc_dense_grads), sizeof(l2hmc_conv3d_grads)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(_lib.DenseNet), C.sizeof(_lib.Conv3DFront), C.sizeof(_lib.GaugePlan), C.sizeof(_lib.MogTarget),
             C.sizeof(_lib.SmallPlan), _lib.DenseNet.packed.offset, _lib.GaugePlan.masks.offset,
-            _lib.GaugePlan.vfront.offset, _lib.SmallPlan.target.offset]
+            _lib.GaugePlan.vfront.offset, _lib.SmallPlan.target.offset, C.sizeof(_lib.DenseGrads),
+            C.sizeof(_lib.Conv3DGrads)]
     assert got == want
 
 
@@ -66,6 +67,38 @@ def test_bad_arguments_are_rejected_on_the_host(L):
     plan = _lib.GaugePlan(T=8, X=8, num_steps=0, hmc=1)
     assert L.l2hmc_gauge_trajectory(C.byref(plan), 1.0, None, None, None, 4, None, None, None, None, None, 0,
                                     None) == 1
+
+
+def test_training_entry_points_check_arguments_on_the_host(L):
+    """The training ABI (include/l2hmc_hip.h, training section): refused before any launch, no GPU needed."""
+    net = _lib.DenseNet(D=128, H=512, Ka=128, Kb=128)
+    hmc = _lib.GaugePlan(T=8, X=8, num_steps=10, hmc=1, xnet=net, vnet=net)
+    assert L.l2hmc_gauge_train_ws_bytes(C.byref(hmc), 64) == 0                     # nothing to train
+    assert L.l2hmc_gauge_train_forward(C.byref(hmc), 1.0, None, None, None, 4, None, None, None, None, None, 0,
+                                       None) == 1
+    plan = _lib.GaugePlan(T=8, X=8, num_steps=10, hmc=0, xnet=net, vnet=net)      # weights are NULL
+    assert L.l2hmc_gauge_train_forward(C.byref(plan), 1.0, None, None, None, 4, None, None, None, None, None, 0,
+                                       None) == 1
+    assert L.l2hmc_gauge_train_backward(C.byref(plan), 1.0, None, 0, None, None, None, None, None, None, None, None,
+                                        None, 0, None) == 1
+    small = _lib.DenseNet(D=32, H=96, Ka=32, Kb=32)
+    bad = _lib.GaugePlan(T=4, X=4, num_steps=2, hmc=0, xnet=small, vnet=net)        # vnet widths do not match D
+    assert L.l2hmc_gauge_train_forward(C.byref(bad), 1.0, None, None, None, 4, None, None, None, None, None, 0,
+                                       None) == 1
+    assert L.l2hmc_gauge_loss_backward(8, 8, 2.0, None, None, None, None, 4, 7, 1., 1., 1., 1., 1., None, None, None,
+                                       None, None) == 1                               # metric code out of range
+    assert L.l2hmc_gauge_loss_backward(8, 8, 2.0, None, None, None, None, 0, 4, 1., 1., 1., 1., 1., None, None, None,
+                                       None, None) == 0                               # empty batch
+    assert L.l2hmc_adam_step(None, None, None, None, -1, 1e-3, .9, .999, 1e-8, None, 0., 0, 0, None) == 1
+    assert L.l2hmc_adam_step(None, None, None, None, 0, 1e-3, .9, .999, 1e-8, None, 0., 0, 0, None) == 0
+    assert L.l2hmc_grad_sumsq(None, 5, 0, 0, None, 0, None) == 1
+    sp = _lib.SmallPlan(x_dim=2, num_nodes=50, trajectory_length=10, hmc=1)
+    assert L.l2hmc_small_train_ws_bytes(C.byref(sp), 64) == 0
+    assert L.l2hmc_small_train_step(C.byref(sp), None, None, None, 8, 0.1, 1., None, None, None, None, None, None, 0,
+                                    None) == 1
+    # training tape of the benchmark shape: 2 x 2048 chains, 10 LF -> about 2.2 GB
+    plan_ws = L.l2hmc_gauge_train_ws_bytes(C.byref(plan), 4096)
+    assert 1.5e9 < plan_ws < 3e9
 
 
 def test_workspace_queries(L):
