@@ -122,3 +122,42 @@ class GaugeSampler:
         if keep_samples:
             out["samples"] = torch.stack(samples).cpu().numpy()
         return out
+
+
+    def save_run(self, out, out_dir, beta, therm_frac=10):
+        """gauge_model.py:1758-2033 (`_save_run_info`) without pickles: the histories returned by `run` go to
+        `observables_steps_{n}_beta_{beta}.npz` and a readable summary -- per-chain means and standard errors of
+        action, plaquette, topological charge and susceptibility after dropping the first steps // therm_frac
+        steps, the charge histogram, mean accept probability, plaquette vs the exact value, integrated
+        autocorrelation time of the plaquette -- to `statistics_steps_{n}_beta_{beta}.txt`.  Returns both paths."""
+        import os
+        from . import stats
+        os.makedirs(out_dir, exist_ok=True)
+        n = int(out["px"].shape[0])
+        arrays = {k: np.asarray(v) for k, v in out.items()
+                  if k in ("px", "actions", "plaqs", "charges", "charge_diff", "samples")}
+        arrays["samples_out"] = out["samples_out"].detach().cpu().numpy()
+        arrays["beta"], arrays["plaq_exact"] = np.float64(beta), np.float64(out["plaq_exact"])
+        npz = os.path.join(out_dir, f"observables_steps_{n}_beta_{beta}.npz")
+        np.savez_compressed(npz, **arrays)
+        (am, ae), (pm, pe), (qm, qe), (sm, se), probs = stats.calc_observables_stats(
+            out["actions"], out["plaqs"], out["charges"], therm_frac=therm_frac)
+        therm = n // therm_frac
+        try:
+            tau = float(stats.integrated_time(out["plaqs"][therm:, :, None], quiet=True)[0][0])
+        except Exception:      # noqa: BLE001 -- too short a run for the estimator
+            tau = float("nan")
+        lines = [f"run of {n} steps, {out['px'].shape[1]} chains, beta = {beta}, thermalisation cut {therm} steps",
+                 f"mean accept probability      : {float(np.mean(out['px'][therm:])):.6f}",
+                 f"average plaquette            : {float(pm.mean()):.6f} +/- {float(np.sqrt(np.mean(pe ** 2) / len(pe))):.6f}"
+                 f"   (exact {float(out['plaq_exact']):.6f}, difference {float(pm.mean() - out['plaq_exact']):+.6f})",
+                 f"average action               : {float(am.mean()):.6f} +/- {float(np.sqrt(np.mean(ae ** 2) / len(ae))):.6f}",
+                 f"topological charge           : {float(qm.mean()):+.6f} +/- {float(np.sqrt(np.mean(qe ** 2) / len(qe))):.6f}",
+                 f"topological susceptibility   : {float(sm.mean()):.6f} +/- {float(np.sqrt(np.mean(se ** 2) / len(se))):.6f}",
+                 f"tunnelling rate |dQ| / step  : {float(np.mean(out['charge_diff'][therm:])):.6f}",
+                 f"tau_int(plaquette)           : {tau:.3f} steps",
+                 "charge probabilities         : " + ", ".join(f"{k:+d}: {v:.4f}" for k, v in probs.items())]
+        txt = os.path.join(out_dir, f"statistics_steps_{n}_beta_{beta}.txt")
+        with open(txt, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        return npz, txt

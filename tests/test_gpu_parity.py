@@ -696,3 +696,19 @@ def test_c_abi_from_plain_c_host_program(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c_abi_demo OK" in out.stdout and "cold start: action 0.000000  avg_plaq 1.000000" in out.stdout
+
+
+def test_sampler_run_is_saved_as_npz_and_statistics_text(la, tmp_path):
+    """f4: observables + statistics on disk (gauge_model.py:1758-2033), npz and text instead of pickles."""
+    T = X = 4
+    xp, vp = H.gauge_weights(T, X, regime="init")
+    orc = H.gauge_oracle(T, X, 3, 0.1, xp, vp)
+    dyn = H.gauge_hip(T, X, 3, 0.1, xp, vp, orc.mask, 16)
+    smp = la.GaugeSampler(dyn)
+    out = smp.run(40, 2.0, keep_samples=True)
+    npz, txt = smp.save_run(out, str(tmp_path), 2.0, therm_frac=4)
+    with np.load(npz, allow_pickle=False) as f:
+        assert f["plaqs"].shape == (40, 16) and f["samples"].shape == (40, 16, 32) and float(f["beta"]) == 2.0
+        np.testing.assert_array_equal(f["px"], out["px"])
+    text = open(txt).read()
+    assert "average plaquette" in text and "exact 0.697775" in text and "charge probabilities" in text
