@@ -12,7 +12,7 @@ from l2hmc_amd import _lib  # noqa: E402
 
 NW = os.environ.get("DIAG_WAVES", "4")
 _lib.LIB_PATH = os.path.join(ROOT, "tools", "_diag", f"libl2hmc_hip_diag_w{NW}.so")
-from tests import helpers as H  # noqa: E402
+import l2hmc_amd as la  # noqa: E402
 
 
 def main():
@@ -21,9 +21,10 @@ def main():
     N, eps, beta = 10, 0.25, 2.0
     L = _lib.lib()
     L.l2hmc_debug_set_stamps.argtypes = [C.c_void_p, C.c_int]
-    xp, vp = H.gauge_weights(T, X, regime="init")
-    masks = H.gauge_oracle(T, X, N, eps, xp, vp).mask
-    dyn = H.gauge_hip(T, X, N, eps, xp, vp, masks, B)
+    np.random.seed(106)
+    lat = la.GaugeLattice(T, X, 2, 'U1', num_samples=B, rand=False)
+    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=eps, hmc=False, network_arch='generic', num_steps=N,
+                           eps_trainable=True)
     x = torch.rand(B, 128, device="cuda") * 6.28
     for _ in range(5):
         dyn(x, beta)
