@@ -173,6 +173,9 @@ int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const flo
  * ------------------------------------------------------------------------ */
 #define L2HMC_PLAN_LAYERED 1   /* never use the fused whole-trajectory kernel */
 #define L2HMC_PLAN_CONV3D 2    /* nets are ConvNet3D: xfront / vfront are set, nets have Ka = Kb = nflat */
+#define L2HMC_PLAN_SELECTED_ONLY 4   /* l2hmc_gauge_mcmc_step integrates only the direction each chain's coin picks:
+                                      * same draws, same outputs as the default whenever the other direction is
+                                      * finite (the reference multiplies it by an exact 0), half the work */
 typedef struct l2hmc_gauge_plan {
   int32_t T, X;            /* lattice extents; D = 2*T*X */
   int32_t num_steps;       /* N_LF */

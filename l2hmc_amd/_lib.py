@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
-PLAN_LAYERED, PLAN_CONV3D = 1, 2
+PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY = 1, 2, 4
 
 
 class DenseNet(C.Structure):

@@ -38,10 +38,51 @@ __global__ __launch_bounds__(256) void step_draws_kernel(float* __restrict__ V, 
   }
 }
 
-// sites % 64 == 0 and 256 % sites == 0.  Xw/Pw: rows [0,B) forward, [B,2B) backward results.
+// Selected-direction variant (L2HMC_PLAN_SELECTED_ONLY): chain b needs only the momentum of the direction its coin
+// picks.  Philox is counter based, so exactly those blocks of the SAME streams are generated: V[b] = elements
+// [(sel*B + b)*D, +D) of the stacked normal stream, with sel = 0 (forward) / 1 (backward) from the coin.
+// D % 4 == 0.  Also writes coin | u (as step_draws_kernel) and dir[b].
+__global__ __launch_bounds__(256) void step_draws_selected_kernel(float* __restrict__ V, float* __restrict__ cu,
+                                                                  int* __restrict__ dir, int64_t B, int D,
+                                                                  uint64_t seed, uint64_t draw) {
+  const int d4n = D >> 2;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < B * d4n; w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = w / d4n;
+    const int d4 = (int)(w - b * d4n);
+    // coin[b] = uniform element b of stream (seed, 2*draw+1)
+    const uint64_t offu = 2 * draw + 1;
+    const int64_t cb = b >> 2;
+    uint32_t c[4] = {(uint32_t)cb, (uint32_t)((uint64_t)cb >> 32), (uint32_t)offu, (uint32_t)(offu >> 32)};
+    philox4x32_10(c, k0, k1);
+    const float coin = (float)(c[b & 3] >> 8) * (1.0f / 16777216.0f);
+    const int sel = coin > 0.5f ? 0 : 1;                       // gauge_dynamics.py:221-227: coin > 0.5 -> forward
+    if (d4 == 0) {
+      cu[b] = coin;
+      const int64_t ub = (B + b) >> 2;
+      uint32_t cu4[4] = {(uint32_t)ub, (uint32_t)((uint64_t)ub >> 32), (uint32_t)offu, (uint32_t)(offu >> 32)};
+      philox4x32_10(cu4, k0, k1);
+      cu[B + b] = (float)(cu4[(B + b) & 3] >> 8) * (1.0f / 16777216.0f);
+      dir[b] = sel;
+    }
+    const uint64_t offn = 2 * draw;
+    const int64_t nb = ((int64_t)(sel ? B + b : b) * D + 4 * d4) >> 2;
+    uint32_t cn[4] = {(uint32_t)nb, (uint32_t)((uint64_t)nb >> 32), (uint32_t)offn, (uint32_t)(offn >> 32)};
+    philox4x32_10(cn, k0, k1);
+    float v[4];
+    philox_normal4(cn, v);
+    float* out = V + b * D + 4 * d4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = v[j];
+  }
+}
+
+// sites % 64 == 0 and 256 % sites == 0.  Xw/Pw: rows [0,B) forward, [boff, boff+B) backward results
+// (boff = B; boff = 0 when only the selected direction was integrated into rows [0,B)).
 __global__ __launch_bounds__(256) void finish_step_kernel(float* __restrict__ x, const float* __restrict__ Xw,
                                                           const float* __restrict__ Pw, const float* __restrict__ cu,
-                                                          int64_t B, int T, int X, int cpw, float* __restrict__ px,
+                                                          int64_t B, int64_t boff, int T, int X, int cpw,
+                                                          float* __restrict__ px,
                                                           float* __restrict__ actions, float* __restrict__ plaqs,
                                                           float* __restrict__ charges, float* __restrict__ dq) {
   __shared__ float2 xs[256];
@@ -60,12 +101,12 @@ __global__ __launch_bounds__(256) void finish_step_kernel(float* __restrict__ x,
   if (live) {
     // gauge_dynamics.py:221-257, arithmetic kept as mask * a + (1 - mask) * b
     const float fm = cu[row] > 0.5f ? 1.f : 0.f, bm = 1.f - fm;
-    p = fm * Pw[row] + bm * Pw[B + row];
+    p = fm * Pw[row] + bm * Pw[boff + row];
     const float am = p > cu[B + row] ? 1.f : 0.f;
     const float2* x2 = reinterpret_cast<const float2*>(x);
     const float2* w2 = reinterpret_cast<const float2*>(Xw);
     xin = x2[row * sites + site];
-    const float2 xf = w2[row * sites + site], xb = w2[(B + row) * sites + site];
+    const float2 xf = w2[row * sites + site], xb = w2[(boff + row) * sites + site];
     const float xp0 = fm * xf.x + bm * xb.x, xp1 = fm * xf.y + bm * xb.y;
     xo.x = am * xp0 + (1.f - am) * xin.x;
     xo.y = am * xp1 + (1.f - am) * xin.y;
@@ -164,21 +205,36 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
   char* rest = base + step_head_bytes(B, D);
   size_t rest_bytes = ws_bytes - step_head_bytes(B, D);
 
+  const bool fused = !(plan->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(plan);
+  const bool fast_finish = sites % kWave == 0 && 256 % sites == 0;
+  const bool selected = (plan->flags & L2HMC_PLAN_SELECTED_ONLY) != 0;
+  if (fused && fast_finish && selected) {
+    // half the rows: the momentum of the chosen direction only (same Philox streams), per-row direction from the coin
+    int* dirs = reinterpret_cast<int*>(Pw + B);                     // second half of the [2B] accept buffer
+    hipLaunchKernelGGL(step_draws_selected_kernel, dim3((unsigned)hmin(ceil_div(B * (D >> 2), 256), 4096)), dim3(256),
+                       0, s, Vw, cu, dirs, B, D, seed, draw);
+    L2HMC_CHECK_LAUNCH("step_draws_selected");
+    if (int e = launch_fused_trajectory(plan, beta, 0, plan->num_steps, x, Vw, dirs, B, Xw, Vw, nullptr, 0, Pw, s))
+      return e;
+    const int cpw = 256 / sites;
+    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, Xw, Pw, cu, B,
+                       (int64_t)0, T, X, cpw, px, actions, plaqs, charges, charge_diff);
+    L2HMC_CHECK_LAUNCH("finish_step");
+    return L2HMC_OK;
+  }
   // momenta of both directions, coin | u  (tf.random_normal :269, tf.random_uniform :223,:246)
   const int64_t nblk = (((int64_t)2 * B * D + 3) >> 2) + ((2 * B + 3) >> 2);
   hipLaunchKernelGGL(step_draws_kernel, dim3((unsigned)hmin(ceil_div(nblk, 256), 4096)), dim3(256), 0, s, Vw,
                      (int64_t)2 * B * D, cu, 2 * B, seed, draw);
   L2HMC_CHECK_LAUNCH("step_draws");
 
-  const bool fused = !(plan->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(plan);
-  const bool fast_finish = sites % kWave == 0 && 256 % sites == 0;
   if (fused && fast_finish) {
     if (int e = launch_fused_trajectory(plan, beta, 0, plan->num_steps, x, Vw, nullptr, 2 * B, Xw, Vw, nullptr, 0, Pw,
                                         s, /*x_mod=*/B, /*dir_split=*/B))
       return e;
     const int cpw = 256 / sites;
-    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, Xw, Pw, cu, B, T, X,
-                       cpw, px, actions, plaqs, charges, charge_diff);
+    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, Xw, Pw, cu, B, B, T,
+                       X, cpw, px, actions, plaqs, charges, charge_diff);
     L2HMC_CHECK_LAUNCH("finish_step");
     return L2HMC_OK;
   }
@@ -190,7 +246,8 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
   rest += 3 * bd;
   rest_bytes -= 3 * bd;
   float* pp = px ? px : Xw;        // Xw / Pw of the head are free here: the transition carves its own copies
-  if (int e = l2hmc_gauge_transition(plan, beta, x, Vw, Vw + (size_t)B * D, cu, cu + B, B, 1, x_prop, v_prop, pp,
+  if (int e = l2hmc_gauge_transition(plan, beta, x, Vw, Vw + (size_t)B * D, cu, cu + B, B, selected ? 0 : 1, x_prop,
+                                     v_prop, pp,
                                      x_out, rest, rest_bytes, stream))
     return e;
   float* q_in = Pw;

@@ -130,7 +130,8 @@ class GaugeDynamics:
     def _plan(self):
         p = _lib.GaugePlan(T=self.lattice.time_size, X=self.lattice.space_size, num_steps=self.num_steps,
                            hmc=int(bool(self.hmc)), eps=float(self.eps),
-                           flags=0 if self.fused else _lib.PLAN_LAYERED,
+                           flags=(0 if self.fused else _lib.PLAN_LAYERED)
+                           | (0 if self.both_directions else _lib.PLAN_SELECTED_ONLY),
                            masks=_lib.dev_ptr(self.mask, name="mask"))
         if not self.hmc:
             p.xnet = self.position_fn.pack()

@@ -36,24 +36,24 @@ class GaugeSampler:
         """One MCMC step on device state x: [B, x_dim].  Returns (x_next, px, observables of x, |dQ|);
         as in the reference the action / plaquette / charge ops look at the step's INPUT samples
         (gauge_model.py:256-266) and dQ compares input and output (:718-725).  Runs as ONE library call
-        (l2hmc_gauge_mcmc_step: draws + both trajectories + mix/accept + observables + wrap)."""
+        (l2hmc_gauge_mcmc_step: draws + trajectories + mix/accept + observables + wrap).  With
+        `dynamics.both_directions = False` the plan carries L2HMC_PLAN_SELECTED_ONLY: each chain is integrated
+        only in the direction its coin picks -- same random streams, same chains, half the work."""
+        import ctypes as C
         dyn = self.dynamics
-        if dyn.both_directions:
-            import ctypes as C
-            x_next = x.clone()
-            B = x.shape[0]
-            outs = {k: torch.empty(B, dtype=torch.float32, device=x.device)
-                    for k in ("px", "action", "avg_plaq", "top_charge", "dq")}
-            plan, L = dyn._plan(), _lib.lib()
-            ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
-            _lib.check(L.l2hmc_gauge_mcmc_step(
-                C.byref(plan), float(beta), x_next.data_ptr(), B, dyn._seed, self._step_count, outs["px"].data_ptr(),
-                outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(), outs["top_charge"].data_ptr(),
-                outs["dq"].data_ptr(), ws, nb, _lib.stream_ptr()))
-            self._step_count += 1
-            self.stats.push(outs["px"], outs["dq"])
-            return x_next, outs["px"], outs, outs["dq"]
-        return self._step_composed(x, beta)
+        x_next = x.clone()
+        B = x.shape[0]
+        outs = {k: torch.empty(B, dtype=torch.float32, device=x.device)
+                for k in ("px", "action", "avg_plaq", "top_charge", "dq")}
+        plan, L = dyn._plan(), _lib.lib()
+        ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
+        _lib.check(L.l2hmc_gauge_mcmc_step(
+            C.byref(plan), float(beta), x_next.data_ptr(), B, dyn._seed, self._step_count, outs["px"].data_ptr(),
+            outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(), outs["top_charge"].data_ptr(),
+            outs["dq"].data_ptr(), ws, nb, _lib.stream_ptr()))
+        self._step_count += 1
+        self.stats.push(outs["px"], outs["dq"])
+        return x_next, outs["px"], outs, outs["dq"]
 
     def _step_composed(self, x, beta):
         """The same step from the separate public ops (used for selected-only mode and as a cross-check)."""

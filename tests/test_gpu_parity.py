@@ -605,7 +605,7 @@ def test_device_resident_sampling_loop(la):
     w = smp.wrap(xs)
     np.testing.assert_allclose(np_(w), np.mod(xs.cpu().numpy(), np.float32(2 * np.pi)), atol=2e-6)
     assert float(w.min()) >= 0 and float(w.max()) < 2 * np.pi + 1e-6
-    # selected-only mode goes through the separate public ops and must give the same kind of step
+    # selected-only mode (L2HMC_PLAN_SELECTED_ONLY) must give the same kind of step
     dyn.both_directions = False
     xa, pxa, obsa, dqa = smp.step(w.clone(), 2.0)
     assert xa.shape == w.shape and float(xa.min()) >= 0 and torch.all((pxa >= 0) & (pxa <= 1))
@@ -712,3 +712,32 @@ def test_sampler_run_is_saved_as_npz_and_statistics_text(la, tmp_path):
         np.testing.assert_array_equal(f["px"], out["px"])
     text = open(txt).read()
     assert "average plaquette" in text and "exact 0.697775" in text and "charge probabilities" in text
+
+
+@pytest.mark.parametrize("arch,fused,B", [("generic", True, 70), ("generic", False, 33), ("conv3D", True, 40)])
+def test_selected_only_step_equals_both_directions_step(la, arch, fused, B):
+    """L2HMC_PLAN_SELECTED_ONLY: every chain is integrated only in the direction its coin picks, with the momentum
+    the both-directions step would have drawn for that direction (same Philox streams) -- the chains must
+    coincide: the reference's mix multiplies the unselected trajectory by an exact 0."""
+    T = X = 8
+    xp, vp = (H.conv_weights if arch == "conv3D" else H.gauge_weights)(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, 4, 0.15, xp, vp, arch=arch)
+    dyn = H.gauge_hip(T, X, 4, 0.15, xp, vp, orc.mask, B, arch=arch)
+    dyn.fused = fused
+    x0 = torch.rand(B, 128, device="cuda") * (2 * np.pi)
+    res = {}
+    for both in (True, False):
+        dyn.both_directions = both
+        smp = la.GaugeSampler(dyn)
+        x, hist = x0.clone(), []
+        for _ in range(3):
+            x, px, obs, dq = smp.step(x, 2.0)
+            hist.append((x.clone(), px.clone(), obs["top_charge"].clone(), dq.clone()))
+        res[both] = hist
+    for a, b in zip(res[True], res[False]):
+        for s_, t_ in zip(a, b):
+            if fused:
+                assert torch.equal(s_, t_)              # per-row arithmetic does not depend on the row's tile mates
+            else:
+                assert H.relerr(np_(t_), np_(s_)) < 1e-6
+    assert 0.2 < float((res[True][0][1] > 0).float().mean()) <= 1.0
