@@ -425,6 +425,14 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
         src1 = fa;
         src2 = fb;
         s1 = SA;
+        if constexpr (TAPE) {      // features (also the reused ones still sitting in fa / fb) -> tape, for d loss / d W1
+          for (int i = tid; i < kFM * (2 * KA / 4); i += kFThreads) {
+            const int rr = i / (2 * KA / 4), c4 = (i - rr * (2 * KA / 4)) * 4;
+            if (rr < nrow)
+              *reinterpret_cast<f32x4*>(tp.feat + (tcr0 + rr) * (2 * KA) + c4) =
+                  *reinterpret_cast<const f32x4*>((c4 < KA ? fa + rr * SA + c4 : fb + rr * SA + (c4 - KA)));
+          }
+        }
       }
       if (l1 == 2) {
 #pragma unroll
@@ -724,7 +732,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
   const bool tape = tape_x && tape_v;
   if (tape) {
-    L2HMC_REQUIRE(!conv && step_begin == 0, "fused trajectory: taping needs a GenericNet plan and the whole trajectory");
+    L2HMC_REQUIRE(step_begin == 0, "fused trajectory: taping needs the whole trajectory");
+    L2HMC_REQUIRE(!conv || (tape_x->feat && tape_v->feat), "fused trajectory: ConvNet3D taping needs the feature tape");
     L2HMC_REQUIRE(tape_x->in && tape_x->h1 && tape_x->h2 && tape_x->stq && tape_x->st && tape_v->in && tape_v->h1 &&
                       tape_v->h2 && tape_v->stq && tape_v->st && tape_x->gate && tape_v->gate,
                   "fused trajectory: NULL tape pointer");
@@ -734,7 +743,10 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
     if (!tape_attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess) {
+                              (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 256, 64, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(float) * CfgC::LDS_FLOATS)) != hipSuccess) {
         set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
         return L2HMC_ERR_HIP;
       }
@@ -747,7 +759,9 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
 #endif
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
-  if (conv)
+  if (conv && tape)
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true, true>), grid, dim3(kFThreads), lds, stream, a);
+  else if (conv)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(kFThreads), lds, stream, a);
   else if (tape)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(kFThreads), lds, stream, a);

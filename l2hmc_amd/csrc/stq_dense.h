@@ -117,6 +117,7 @@ struct FusedTape {
   float* h2;    // [calls][rows][H]
   float* stq;   // [calls][3][rows][D]
   float* st;    // [calls][rows][D]
+  float* feat;  // ConvNet3D plans: [calls][rows][Ka+Kb] front-end features (NULL otherwise)
   unsigned* gate;   // [calls][2 layers][workgroups][256 threads]: relu masks of h1 / h2 in the lane's own C-fragment
                     // order (bit t*4+e), so the fused reverse pass gates its deltas with one 4-byte load per layer
 };
@@ -128,6 +129,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
 // whole-trajectory reverse pass (fused_train.hip); deltas_*: {dout, d2, d1} tapes, coef_parts: {dcs_x, dcq_x, dcs_v, dcq_v}
 size_t fused_bwd_pack_floats(const l2hmc_dense_net* n);
 int fused_train_supported(const l2hmc_gauge_plan* p);
+int fused_train_forward_supported(const l2hmc_gauge_plan* p);
 int launch_fused_train_backward(const l2hmc_gauge_plan* p, float beta, const int* dir, int64_t rows, float* dx,
                                 float* dv, const float* dld, const FusedTape& tx, const FusedTape& tv,
                                 float* const deltas_x[3], float* const deltas_v[3], float* pack_x, float* pack_v,

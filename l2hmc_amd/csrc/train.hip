@@ -980,9 +980,9 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
   L2HMC_CHECK_LAUNCH("invert_mask");
   float* x = x_out;
   float* v = v_out;
-  if (fused_train_supported(plan)) {
+  if (fused_train_forward_supported(plan)) {
     // whole-trajectory kernel (fused_traj.hip) writing the same tape: one launch instead of ~6 per network call
-    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.gate};
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.feat, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.feat, w.v.gate};
     return launch_fused_trajectory(plan, beta, 0, N, x, v, dir, rows, x, v, sumlogdet, 0, p_accept, s, 0, 0, &tx, &tv);
   }
   if (int e = launch_u1_action_force(x, rows, plan->T, plan->X, beta, w.act0, nullptr, nullptr, nullptr, s)) return e;
@@ -1101,7 +1101,7 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
   int64_t ncoef = nblk;            // workgroups that wrote coefficient / step-size partials
   if (fused_bwd) {
     // one launch for the whole reverse data path (fused_train.hip)
-    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.gate};
+    const FusedTape tx{w.x.in, w.x.h1, w.x.h2, w.x.stq, w.x.st, w.x.feat, w.x.gate}, tv{w.v.in, w.v.h1, w.v.h2, w.v.stq, w.v.st, w.v.feat, w.v.gate};
     float* const dxs_[3] = {w.x.dout, w.x.d2, w.x.d1};
     float* const dvs_[3] = {w.v.dout, w.v.d2, w.v.d1};
     float* const coef[4] = {w.x.dcs_part, w.x.dcq_part, w.v.dcs_part, w.v.dcq_part};
