@@ -210,6 +210,31 @@ def main():
         out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
                                         "chain_leapfrog_steps_per_s": BATCH * N_LF / tcd}
 
+    # ---- secondary: BASELINE.json configs[1], the 2-D mixture of Gaussians (mog_model.py): 4096 chains per GPU,
+    #      10 LF steps, `propose` = forward + backward trajectories of every chain in one launch + mix/accept.
+    #      Chains are independent: every rank runs its own 4096 (no collective); rank 0 reports its own time.
+    try:
+        import l2hmc_amd as la
+        np.random.seed(106)
+        gmm = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+        mdyn = la.Dynamics(2, gmm.get_energy_function(), trajectory_length=10, eps=0.1,
+                           net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=50))
+        mx = torch.randn(4096, 2, device=dev)
+        for _ in range(5):
+            mx = la.propose(mx, mdyn, do_mh_step=True)[3][0]
+        torch.cuda.synchronize()
+        tm0 = time.perf_counter()
+        for _ in range(50):
+            mx = la.propose(mx, mdyn, do_mh_step=True)[3][0]
+        torch.cuda.synchronize()
+        tmd = (time.perf_counter() - tm0) / 50
+        out["config"]["mog_cfg2"] = {
+            "workload": "2-D mixture of Gaussians, 4096 chains per GPU, 10 LF steps, MLP H=50 (BASELINE.json configs[1])",
+            "ms_per_propose": 1e3 * tmd, "chain_leapfrog_steps_per_s": world * 4096 * 10 / tmd,
+            "bound": "latency / VALU (x_dim 2, 50 hidden units: no MFMA tile fits; DESIGN.md K4)"}
+    except Exception as e:                        # noqa: BLE001
+        out["config"]["mog_cfg2"] = {"error": repr(e)}
+
     # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
     #      takes part because the gradient bucket is all-reduced (f1/f2) ----
     if not args.no_train:
