@@ -66,13 +66,15 @@ def conv3d_net(p, inputs, T, X):
 class TorchGaugeModel:
     """Weights and eps are leaf tensors with requires_grad=True."""
 
-    def __init__(self, T, X, num_steps, eps, masks, xnet, vnet, arch='generic'):
-        self.arch = arch
+    def __init__(self, T, X, num_steps, eps, masks, xnet, vnet, arch='generic', dtype=torch.float64):
+        # dtype=torch.float32 evaluates the same graph in the reference's precision: the yardstick for how far an
+        # fp32 implementation may sit from the float64 answer on chaotic trajectories
+        self.arch, self.dtype = arch, dtype
         self.T, self.X, self.N = T, X, num_steps
-        self.eps = torch.tensor(float(eps), dtype=torch.float64, requires_grad=True)
-        self.mask = torch.tensor(np.asarray(masks), dtype=torch.float64)
-        self.xnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in xnet.items()}
-        self.vnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in vnet.items()}
+        self.eps = torch.tensor(float(eps), dtype=dtype, requires_grad=True)
+        self.mask = torch.tensor(np.asarray(masks), dtype=dtype)
+        self.xnet = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in xnet.items()}
+        self.vnet = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in vnet.items()}
 
     def _force(self, x, beta):
         return beta * grad_action(x, self.T, self.X)
@@ -88,7 +90,7 @@ class TorchGaugeModel:
 
     def _time(self, i, B):
         arg = TWO_PI * i / self.N
-        return torch.tensor([[np.cos(arg), np.sin(arg)]], dtype=torch.float64).repeat(B, 1)
+        return torch.tensor([[np.cos(arg), np.sin(arg)]], dtype=self.dtype).repeat(B, 1)
 
     def _upd_v(self, x, v, beta, t, bwd):
         g = self._force(x, beta)
@@ -128,24 +130,24 @@ class TorchGaugeModel:
 
     def trajectory(self, x0, v0, beta, bwd):
         x, v = x0, v0
-        ld = torch.zeros(x.shape[0], dtype=torch.float64)
+        ld = torch.zeros(x.shape[0], dtype=self.dtype)
         for step in range(self.N):
             x, v, j = self.leapfrog(x, v, beta, step, bwd)
             ld = ld + j
         h0 = self._energy(x0, beta) + 0.5 * (v0 ** 2).sum(1)
         h1 = self._energy(x, beta) + 0.5 * (v ** 2).sum(1)
-        p = torch.exp(torch.minimum(h0 - h1 + ld, torch.zeros((), dtype=torch.float64)))
+        p = torch.exp(torch.minimum(h0 - h1 + ld, torch.zeros((), dtype=self.dtype)))
         return x, v, torch.where(torch.isfinite(p), p, torch.zeros_like(p)), ld
 
     def apply_transition(self, x, beta, v0f, v0b, coin, u):
         xf, vf, pf, _ = self.trajectory(x, v0f, beta, False)
         xb, vb, pb, _ = self.trajectory(x, v0b, beta, True)
-        fm = (coin > 0.5).double()
+        fm = (coin > 0.5).to(self.dtype)
         bm = 1. - fm
         xp = fm[:, None] * xf + bm[:, None] * xb
         vp = fm[:, None] * vf + bm[:, None] * vb
         p = fm * pf + bm * pb
-        am = (p > u).double()
+        am = (p > u).to(self.dtype)
         return xp, vp, p, am[:, None] * xp + (1. - am)[:, None] * x
 
     def loss(self, x, z, beta, draws_x, draws_z, metric='cos_diff', loss_scale=1., aux_weight=1., std_weight=1.,
@@ -198,7 +200,7 @@ class TorchDynamicsModel(TorchGaugeModel):
     energy with closed-form gradient (what tf.gradients of :151-158 evaluates to), temperature."""
 
     def __init__(self, target, num_steps, eps, masks, xnet, vnet, temperature=1.0):
-        self.arch, self.N = 'mlp', num_steps
+        self.arch, self.N, self.dtype = 'mlp', num_steps, torch.float64
         self.alpha = torch.tensor(float(np.log(eps)), dtype=torch.float64, requires_grad=True)
         self.mask = torch.tensor(np.asarray(masks), dtype=torch.float64)
         self.xnet = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in xnet.items()}
