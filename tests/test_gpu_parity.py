@@ -741,3 +741,43 @@ def test_selected_only_step_equals_both_directions_step(la, arch, fused, B):
             else:
                 assert H.relerr(np_(t_), np_(s_)) < 1e-6
     assert 0.2 < float((res[True][0][1] > 0).float().mean()) <= 1.0
+
+
+def test_mcmc_step_is_hip_graph_capturable(la):
+    """include/l2hmc_hip.h promises no allocation / synchronisation inside the library: a whole MCMC step
+    (draws + trajectories + mix/accept + observables + wrap) is captured into a HIP graph and replayed."""
+    import ctypes as C
+    from l2hmc_amd import _lib
+    T = X = 8
+    B = 64
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, 3, 0.1, xp, vp)
+    dyn = H.gauge_hip(T, X, 3, 0.1, xp, vp, orc.mask, B)
+    plan, L = dyn._plan(), _lib.lib()
+    nb = L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    x0 = torch.rand(B, 128, device="cuda") * (2 * np.pi)
+    outs = [torch.empty(B, device="cuda") for _ in range(5)]
+
+    def step(x):
+        _lib.check(L.l2hmc_gauge_mcmc_step(C.byref(plan), 2.0, x.data_ptr(), B, 42, 7, *(o.data_ptr() for o in outs),
+                                           ws.data_ptr(), nb, _lib.stream_ptr()))
+    eager = x0.clone()
+    step(eager)                                   # also the warm-up (one-time function attributes are set here)
+    torch.cuda.synchronize()
+    want_px = outs[0].clone()
+    xg = x0.clone()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            step(xg)
+    torch.cuda.current_stream().wait_stream(side)
+    xg.copy_(x0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xg, eager) and torch.equal(outs[0], want_px)
+    g.replay()                                    # a second replay advances the chains from the first one's output
+    torch.cuda.synchronize()
+    assert not torch.equal(xg, eager) and float(xg.min()) >= 0.0
