@@ -57,10 +57,12 @@ __device__ void load_net(const l2hmc_dense_net& n, float* L, int dim) {
 // (S, T, Q) = net([a, b, t]) for the chain this lane belongs to.  `sub` = lane within the chain (0..15),
 // `hrow` = the chain's HP-float LDS row for the hidden-vector exchange.  Must be called by all threads of the
 // workgroup (it contains workgroup barriers).
-template <int HP>
-__device__ void net_eval(const float* L, int dim, int q_tanh, const float a[kMaxDim], const float b[kMaxDim],
-                         float tc, float ts, int sub, float* hrow, float S[kMaxDim], float T[kMaxDim],
-                         float Q[kMaxDim]) {
+// MD: compile-time bound on x_dim (2 for the benchmark targets, kMaxDim otherwise); register arrays and the
+// unrolled loops are sized by it.
+template <int HP, int MD = L2HMC_MAX_SMALL_DIM>
+__device__ void net_eval(const float* L, int dim, int q_tanh, const float* a, const float* b, float tc, float ts,
+                         int sub, float* hrow, float* S, float* T, float* Q) {
+  constexpr int kMaxDim = MD;
   constexpr int UPL = HP / kLPC;           // hidden units per lane: n = sub * UPL + j
   const SmallNetView v = small_net_view(HP, dim);
   const int n0 = sub * UPL;
@@ -130,9 +132,11 @@ __host__ __device__ inline TargetView target_view(int dim, int K) {
   return t;
 }
 
-// distributions.py:151-158 (GMM), :63-68 (Gaussian); gradient in closed form.
-__device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gaussian, float inv_temp,
-                            const float x[kMaxDim], float* E, float g[kMaxDim]) {
+// distributions.py:151-158 (GMM), :63-68 (Gaussian); gradient in closed form.  All loops over the dimension run
+// to the compile-time bound MD with a guard, so x / g stay in registers (no dynamically indexed arrays).
+template <int MD = L2HMC_MAX_SMALL_DIM>
+__device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gaussian, float inv_temp, const float* x,
+                                   float* E, float* g) {
   const TargetView tv = target_view(dim, K);
   float V[kMaxMix];
   float vmax = -INFINITY;
@@ -140,10 +144,15 @@ __device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gauss
   for (int k = 0; k < kMaxMix; ++k) {
     if (k < K) {
       float quad = 0.f;
-      for (int i = 0; i < dim; ++i) {
-        float pd = 0.f;
-        for (int j = 0; j < dim; ++j) pd += Lt[tv.prec + (k * dim + i) * dim + j] * (x[j] - Lt[tv.mu + k * dim + j]);
-        quad += (x[i] - Lt[tv.mu + k * dim + i]) * pd;
+#pragma unroll
+      for (int i = 0; i < MD; ++i) {
+        if (i < dim) {
+          float pd = 0.f;
+#pragma unroll
+          for (int j = 0; j < MD; ++j)
+            if (j < dim) pd += Lt[tv.prec + (k * dim + i) * dim + j] * (x[j] - Lt[tv.mu + k * dim + j]);
+          quad += (x[i] - Lt[tv.mu + k * dim + i]) * pd;
+        }
       }
       V[k] = -0.5f * quad + (is_gaussian ? 0.f : Lt[tv.logc + k]);
       vmax = fmaxf(vmax, V[k]);
@@ -151,19 +160,22 @@ __device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gauss
   }
   float sw = 0.f;
 #pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) g[d] = 0.f;
+  for (int d = 0; d < MD; ++d) g[d] = 0.f;
 #pragma unroll
   for (int k = 0; k < kMaxMix; ++k) {
     if (k < K) {
       const float w = is_gaussian ? 1.f : expf(V[k] - vmax);
       sw += w;
 #pragma unroll
-      for (int i = 0; i < kMaxDim; ++i) {
+      for (int i = 0; i < MD; ++i) {
         if (i < dim) {
           float gi = 0.f;
-          for (int j = 0; j < dim; ++j) {
-            const float dj = x[j] - Lt[tv.mu + k * dim + j];
-            gi += (Lt[tv.prec + (k * dim + i) * dim + j] + Lt[tv.prec + (k * dim + j) * dim + i]) * dj;
+#pragma unroll
+          for (int j = 0; j < MD; ++j) {
+            if (j < dim) {
+              const float dj = x[j] - Lt[tv.mu + k * dim + j];
+              gi += (Lt[tv.prec + (k * dim + i) * dim + j] + Lt[tv.prec + (k * dim + j) * dim + i]) * dj;
+            }
           }
           g[i] += w * 0.5f * gi;
         }
@@ -173,7 +185,7 @@ __device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gauss
   const float e = is_gaussian ? -V[0] : -(vmax + logf(sw));
   *E = e * inv_temp;
 #pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) g[d] = g[d] / sw * inv_temp;
+  for (int d = 0; d < MD; ++d) g[d] = g[d] / sw * inv_temp;
 }
 
 __device__ inline void load_target(const l2hmc_mog_target& t, float* Lt) {

@@ -46,8 +46,9 @@ struct SmallTrajArgs {
   float* x_out; float* v_out; float* sumlogdet; float* p_accept;
 };
 
-template <int HP>
+template <int HP, int MD>
 __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs a) {
+  constexpr int kMaxDim = MD;      // shadows the library-wide bound: register arrays / unrolled loops of this instance
   extern __shared__ float lds[];
   const l2hmc_small_plan& P = a.plan;
   const int dim = P.x_dim, N = P.trajectory_length;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
     v[d] = (d < dim && live) ? a.v0[r * dim + d] : 0.f;
   }
   float g[kMaxDim], E0, E1;
-  energy_grad(Lt, dim, K, isg, inv_temp, x, &E0, g);
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E0, g);
   float kin0 = 0.f;
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) kin0 += v[d] * v[d];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
             const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
             bin[d] = k * x[d];
           }
-          if (!P.hmc) net_eval<HP>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
+          if (!P.hmc) net_eval<HP, MD>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
           for (int d = 0; d < kMaxDim; ++d) {
             if (d < dim) {
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
             }
           }
         }
-        energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+        energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
       }
-      if (!P.hmc) net_eval<HP>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
+      if (!P.hmc) net_eval<HP, MD>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) {
         if (d < dim) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
       }
     }
   }
-  energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
   float kin1 = 0.f;
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) kin1 += v[d] * v[d];
@@ -213,16 +214,25 @@ extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float*
   const dim3 grid((unsigned)ceil_div(rows, kSmallThreads / kLPC));
   static bool attr_set = false;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16, kMaxDim>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (HP == 16)
-    hipLaunchKernelGGL(small_traj_kernel<16>, grid, dim3(kSmallThreads), lds, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(small_traj_kernel<64>, grid, dim3(kSmallThreads), lds, (hipStream_t)stream, a);
+  const dim3 blk(kSmallThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (dim <= 2) {       // the benchmark targets: x_dim 2 instance (chain state and S/T/Q entirely in registers)
+    if (HP == 16) hipLaunchKernelGGL((small_traj_kernel<16, 2>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((small_traj_kernel<64, 2>), grid, blk, lds, st, a);
+  } else {
+    if (HP == 16) hipLaunchKernelGGL((small_traj_kernel<16, kMaxDim>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((small_traj_kernel<64, kMaxDim>), grid, blk, lds, st, a);
+  }
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;
 }

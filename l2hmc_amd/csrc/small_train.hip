@@ -25,18 +25,20 @@
 namespace l2hmc {
 
 constexpr int kSlots = kSmallThreads / kLPC;   // chains per workgroup
-constexpr int kMisc = 8 * kMaxDim + 8;         // per-slot row: a, b (2 dim) | tc ts | dout (3 dim) | dSS dQQ (2 dim)
+// per-slot LDS row: a, b (2 MD) | tc ts | dout (3 MD) | dSS dQQ (2 MD)
+constexpr int small_misc(int MD) { return 8 * MD + 8; }
 
-template <int HP>
+template <int HP, int MD>
 struct SmallAcc {   // per-thread weight-gradient accumulators of one network
+  static constexpr int kMaxDim = MD;
   float wh[HP * HP / kSmallThreads > 0 ? HP * HP / kSmallThreads : 1];
   float w1[((2 * kMaxDim + 2) * HP + kSmallThreads - 1) / kSmallThreads];
   float whd[(3 * kMaxDim * HP + kSmallThreads - 1) / kSmallThreads];
   float b1, bh, bhd, cs, cq;
 };
 
-template <int HP>
-__device__ __forceinline__ void acc_zero(SmallAcc<HP>& a) {
+template <int HP, int MD>
+__device__ __forceinline__ void acc_zero(SmallAcc<HP, MD>& a) {
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(a.wh) / 4); ++i) a.wh[i] = 0.f;
 #pragma unroll
@@ -47,9 +49,10 @@ __device__ __forceinline__ void acc_zero(SmallAcc<HP>& a) {
 }
 
 // one network call's contribution of the workgroup's sixteen chains, slot order
-template <int HP>
-__device__ __forceinline__ void acc_add(SmallAcc<HP>& a, int dim, const float* Rh1, const float* Rh2,
+template <int HP, int MD>
+__device__ __forceinline__ void acc_add(SmallAcc<HP, MD>& a, int dim, const float* Rh1, const float* Rh2,
                                         const float* Rd1, const float* Rd2, const float* Rm) {
+  constexpr int kMaxDim = MD, kMisc = small_misc(MD);
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(a.wh) / 4); ++i) {
@@ -121,8 +124,10 @@ __host__ __device__ inline int small_grad_floats(int H, int dim) {
   return H * 2 * dim + 2 * H + H + H * H + H + 3 * dim * H + 3 * dim + 2 * dim;
 }
 
-template <int HP>
-__device__ __forceinline__ void acc_store(const SmallAcc<HP>& a, int H, int dim, float* out) {
+template <int HP, int MD>
+__device__ __forceinline__ void acc_store(const SmallAcc<HP, MD>& a, int H, int dim, float* out) {
+  constexpr int kMaxDim = MD;
+  (void)kMaxDim;
   const int tid = threadIdx.x;
   float* w1 = out;
   float* wt = w1 + H * 2 * dim;
@@ -172,10 +177,10 @@ __device__ __forceinline__ void acc_store(const SmallAcc<HP>& a, int H, int dim,
 }
 
 // network evaluation that also returns this lane's hidden units (post-relu)
-template <int HP>
-__device__ void net_eval_keep(const float* L, int dim, int q_tanh, const float a[kMaxDim], const float b[kMaxDim],
-                              float tc, float ts, int sub, float* hrow, float h1[HP / kLPC], float h2[HP / kLPC],
-                              float S[kMaxDim], float T[kMaxDim], float Q[kMaxDim]) {
+template <int HP, int MD>
+__device__ void net_eval_keep(const float* L, int dim, int q_tanh, const float* a, const float* b, float tc, float ts,
+                              int sub, float* hrow, float* h1, float* h2, float* S, float* T, float* Q) {
+  constexpr int kMaxDim = MD;
   constexpr int UPL = HP / kLPC;
   const SmallNetView v = small_net_view(HP, dim);
   const int n0 = sub * UPL;
@@ -236,8 +241,10 @@ __device__ void net_eval_keep(const float* L, int dim, int q_tanh, const float a
 // Hessian(energy)(x) . u for the mixture / Gaussian target (second derivative of distributions.py:151-158):
 //   H = sum_k r_k P_k - sum_k r_k g_k g_k^T + gbar gbar^T,   g_k = P_k (x - mu_k), r = softmax(V), gbar = sum r_k g_k
 // with P_k the symmetrised precision; everything divided by the temperature.
-__device__ inline void energy_hvp(const float* Lt, int dim, int K, int is_gaussian, float inv_temp,
-                                  const float x[kMaxDim], const float u[kMaxDim], float out[kMaxDim]) {
+template <int MD>
+__device__ inline void energy_hvp(const float* Lt, int dim, int K, int is_gaussian, float inv_temp, const float* x,
+                                  const float* u, float* out) {
+  constexpr int kMaxDim = MD;
   const TargetView tv = target_view(dim, K);
   float V[kMaxMix];
   float vmax = -INFINITY;
@@ -245,10 +252,15 @@ __device__ inline void energy_hvp(const float* Lt, int dim, int K, int is_gaussi
   for (int k = 0; k < kMaxMix; ++k) {
     if (k < K) {
       float quad = 0.f;
-      for (int i = 0; i < dim; ++i) {
-        float pd = 0.f;
-        for (int j = 0; j < dim; ++j) pd += Lt[tv.prec + (k * dim + i) * dim + j] * (x[j] - Lt[tv.mu + k * dim + j]);
-        quad += (x[i] - Lt[tv.mu + k * dim + i]) * pd;
+#pragma unroll
+      for (int i = 0; i < kMaxDim; ++i) {
+        if (i < dim) {
+          float pd = 0.f;
+#pragma unroll
+          for (int j = 0; j < kMaxDim; ++j)
+            if (j < dim) pd += Lt[tv.prec + (k * dim + i) * dim + j] * (x[j] - Lt[tv.mu + k * dim + j]);
+          quad += (x[i] - Lt[tv.mu + k * dim + i]) * pd;
+        }
       }
       V[k] = -0.5f * quad + (is_gaussian ? 0.f : Lt[tv.logc + k]);
       vmax = fmaxf(vmax, V[k]);
@@ -270,10 +282,13 @@ __device__ inline void energy_hvp(const float* Lt, int dim, int K, int is_gaussi
       for (int i = 0; i < kMaxDim; ++i) {
         gk[i] = pu[i] = 0.f;
         if (i < dim) {
-          for (int j = 0; j < dim; ++j) {
-            const float ps = 0.5f * (Lt[tv.prec + (k * dim + i) * dim + j] + Lt[tv.prec + (k * dim + j) * dim + i]);
-            gk[i] += ps * (x[j] - Lt[tv.mu + k * dim + j]);
-            pu[i] += ps * u[j];
+#pragma unroll
+          for (int j = 0; j < kMaxDim; ++j) {
+            if (j < dim) {
+              const float ps = 0.5f * (Lt[tv.prec + (k * dim + i) * dim + j] + Lt[tv.prec + (k * dim + j) * dim + i]);
+              gk[i] += ps * (x[j] - Lt[tv.mu + k * dim + j]);
+              pu[i] += ps * u[j];
+            }
           }
           gu += gk[i] * u[i];
         }
@@ -304,8 +319,9 @@ struct SmallTrainArgs {
   float* part;        // [workgroups][2 * gsize + 1]: xnet gradient | vnet gradient | d loss / d eps
 };
 
-template <int HP>
+template <int HP, int MD>
 __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainArgs a) {
+  constexpr int kMaxDim = MD, kMisc = small_misc(MD);      // shadow the library-wide bound for this instance
   constexpr int UPL = HP / kLPC;
   extern __shared__ float lds[];
   const l2hmc_small_plan& P = a.plan;
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
     xs[d] = x[d];
   }
   float g[kMaxDim], E0, E1;
-  energy_grad(Lt, dim, K, isg, inv_temp, x, &E0, g);
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E0, g);
   float kin0 = 0.f;
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) kin0 += v[d] * v[d];
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
               tp[2 * dim + d] = x[d];
             }
           }
-          net_eval<HP>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
+          net_eval<HP, MD>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
           for (int d = 0; d < kMaxDim; ++d) {
             if (d < dim) {
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
             }
           }
         }
-        energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+        energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
       }
       float* tp = mytape + (size_t)(it * 4 + (half ? 3 : 0)) * 3 * dim;
       if (lsub == 0) {
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
             tp[2 * dim + d] = v[d];
           }
       }
-      net_eval<HP>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
+      net_eval<HP, MD>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) {
         if (d < dim) {
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
       }
     }
   }
-  energy_grad(Lt, dim, K, isg, inv_temp, x, &E1, g);
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
   float kin1 = 0.f;
 #pragma unroll
   for (int d = 0; d < kMaxDim; ++d) kin1 += v[d] * v[d];
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   float deps = 0.f;
 
   // ------------------------------------------------------------------ reverse pass
-  SmallAcc<HP> accX, accV;
+  SmallAcc<HP, MD> accX, accV;
   acc_zero(accX);
   acc_zero(accV);
   for (int c = ncalls - 1; c >= 0; --c) {
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
       bin[d] = d < dim ? tp[dim + d] : 0.f;
       st[d] = d < dim ? tp[2 * dim + d] : 0.f;
     }
-    net_eval_keep<HP>(L, dim, q_tanh, ain, bin, tc, ts, lsub, hrow, h1, h2, S, T, Q);
+    net_eval_keep<HP, MD>(L, dim, q_tanh, ain, bin, tc, ts, lsub, hrow, h1, h2, S, T, Q);
     const SmallNetView nvw = small_net_view(HP, dim);
     // ---- sub-update backward -> head pre-activation gradients (replicated over the chain's lanes)
     float dS[kMaxDim], dT[kMaxDim], dQ[kMaxDim], dgd[kMaxDim], keep[kMaxDim];
@@ -623,14 +639,14 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
       rm[2 * kMaxDim + 1] = live ? ts : 0.f;
     }
     __syncthreads();
-    if (vcall) acc_add<HP>(accV, dim, Rh1, Rh2, Rd1, Rd2, Rm);
-    else acc_add<HP>(accX, dim, Rh1, Rh2, Rd1, Rd2, Rm);
+    if (vcall) acc_add<HP, MD>(accV, dim, Rh1, Rh2, Rd1, Rd2, Rm);
+    else acc_add<HP, MD>(accX, dim, Rh1, Rh2, Rd1, Rd2, Rm);
     // ---- into the upstream gradients
     if (vcall) {
       float u[kMaxDim], hv[kMaxDim];
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) u[d] = dgd[d] + db[d];
-      energy_hvp(Lt, dim, K, isg, inv_temp, ain, u, hv);
+      energy_hvp<MD>(Lt, dim, K, isg, inv_temp, ain, u, hv);
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) dx[d] += da[d] + hv[d];
     } else {
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   // ------------------------------------------------------------------ partial gradients of this workgroup
   const int gsize = small_grad_floats(H, dim);
   float* out = a.part + (size_t)blockIdx.x * (2 * gsize + 1);
-  acc_store<HP>(accX, H, dim, out);
-  acc_store<HP>(accV, H, dim, out + gsize);
+  acc_store<HP, MD>(accX, H, dim, out);
+  acc_store<HP, MD>(accV, H, dim, out + gsize);
   __syncthreads();
   if (lsub == 0) Rm[slot * kMisc] = live ? deps : 0.f;
   __syncthreads();
@@ -669,8 +685,9 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(const float* __restri
   if (sl == 0 && i < count) out[i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
-template <int HP>
+template <int HP, int MD>
 static size_t small_train_lds(int dim, int K, int N) {
+  constexpr int kMisc = small_misc(MD);
   return sizeof(float) * (2 * (size_t)small_net_view(HP, dim).size + 2 * (size_t)HP * HP + target_view(dim, K).size +
                           ((N * dim + 3) & ~3) + 5 * (size_t)kSlots * HP + (size_t)kSlots * kMisc +
                           (size_t)kSlots * 4 * N * 3 * dim);
@@ -713,21 +730,34 @@ extern "C" int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float*
     return L2HMC_ERR_WORKSPACE;
   }
   const int HP = H <= 16 ? 16 : 64;
-  const size_t lds = HP == 16 ? small_train_lds<16>(dim, plan->target.K, N) : small_train_lds<64>(dim, plan->target.K, N);
+  const bool d2 = dim <= 2;          // x_dim 2 instance for the benchmark targets
+  const size_t lds = d2 ? (HP == 16 ? small_train_lds<16, 2>(dim, plan->target.K, N) : small_train_lds<64, 2>(dim, plan->target.K, N))
+                        : (HP == 16 ? small_train_lds<16, kMaxDim>(dim, plan->target.K, N)
+                                    : small_train_lds<64, kMaxDim>(dim, plan->target.K, N));
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_train_step: LDS image %zu B too large (trajectory too long?)", lds);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16, kMaxDim>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
   const int nwg = (int)ceil_div(rows, kSlots);
   SmallTrainArgs a{*plan, x0, v0, dir, rows, scale, inv_count, x_out, v_out, p_accept, terms, static_cast<float*>(ws)};
-  if (HP == 16) hipLaunchKernelGGL(small_train_kernel<16>, dim3(nwg), dim3(kSmallThreads), lds, s, a);
-  else hipLaunchKernelGGL(small_train_kernel<64>, dim3(nwg), dim3(kSmallThreads), lds, s, a);
+  const dim3 blk(kSmallThreads);
+  if (d2) {
+    if (HP == 16) hipLaunchKernelGGL((small_train_kernel<16, 2>), dim3(nwg), blk, lds, s, a);
+    else hipLaunchKernelGGL((small_train_kernel<64, 2>), dim3(nwg), blk, lds, s, a);
+  } else {
+    if (HP == 16) hipLaunchKernelGGL((small_train_kernel<16, kMaxDim>), dim3(nwg), blk, lds, s, a);
+    else hipLaunchKernelGGL((small_train_kernel<64, kMaxDim>), dim3(nwg), blk, lds, s, a);
+  }
   L2HMC_CHECK_LAUNCH("small_train");
   const int64_t count = 2 * (int64_t)small_grad_floats(H, dim) + 1;
   hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)ceil_div(count, 64)), dim3(256), 0, s,
