@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
   const int c0 = fl * 8;                           // this thread's 8 columns in the element-wise phases
   const bool live = fc < nrow;
   const int T = p.T, X = p.X, N = p.num_steps;
+  const int xsh = 31 - __clz(X);       // X is a power of two whenever this kernel is chosen (fused_plan_supported)
 
   for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
     const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
         const float* xc = xs + fc * SX;
         const float* uc = us + fc * SX;
         for (int s = fl; s < sites; s += kTPC) {
-          const int i = s / X, j = s - i * X;
+          const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
           const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
           const int e0 = 2 * s, er = 2 * (i * X + jp), ed = 2 * (ip * X + j);
           const float P = xc[e0] - xc[e0 + 1] - xc[er] + xc[ed + 1];
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
         __syncthreads();
         const float* spc = sp + fc * SP;
         for (int s = fl; s < sites; s += kTPC) {
-          const int i = s / X, j = s - i * X;
+          const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
           const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
           const float c = spc[s];
           dxs[fc * SX + 2 * s] += dis[fc * SI + 2 * s] + p.beta * (c - spc[i * X + jm]);

@@ -243,12 +243,13 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     return v;
   };
   const int T = p.T, X = p.X;
+  const int xsh = 31 - __clz(X);       // sites = 64 and X divides it: shifts instead of run-time divisions
   // force (beta * dS/dx) into gs; returns this chain's action (all 16 lanes of the chain)
   auto force_pass = [&]() -> float {
     const float* xc = xs + fc * SX;
     float act = 0.f;
     for (int s = fl; s < sites; s += kTPC) {
-      const int i = s / X, j = s - i * X;
+      const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
       const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
       const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
       float sn, cs;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     float* gc = gs + fc * SX;
     const float* spc = sp + fc * SP;
     for (int s = fl; s < sites; s += kTPC) {
-      const int i = s / X, j = s - i * X;
+      const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
       const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
       const float sP = spc[s];
       gc[2 * s] = p.beta * (sP - spc[i * X + jm]);
@@ -694,7 +695,7 @@ static int fused_conv_net(const l2hmc_dense_net* n) {
 int fused_net_supported(const l2hmc_dense_net* n) { return fused_generic_net(n) || fused_conv_net(n); }
 
 int fused_plan_supported(const l2hmc_gauge_plan* p) {
-  if (p->hmc || !p->xnet.packed || !p->vnet.packed || 2 * p->T * p->X != 128) return 0;
+  if (p->hmc || !p->xnet.packed || !p->vnet.packed || 2 * p->T * p->X != 128 || (p->X & (p->X - 1)) != 0) return 0;
   if (p->flags & L2HMC_PLAN_CONV3D)
     return fused_conv_net(&p->xnet) && fused_conv_net(&p->vnet) && p->T == 8 && p->X == 8 && p->xfront.F == 8 &&
            p->vfront.F == 8;
