@@ -424,16 +424,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
   const int64_t re = rb + chunk < Rt ? rb + chunk : Rt;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
   if (active) {
+    // (call, row) of the taped row, advanced incrementally: one 64-bit division per thread instead of one per row
+    int64_t call = timed ? (rb + rl) / rows : 0, row = timed ? (rb + rl) - call * rows : 0;
 #pragma unroll 4
     for (int64_t rr = rb + rl; rr < re; rr += rpp) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + rr * n + c0 + cl * 4);
       s0 += v;
       if (timed) {
-        const int64_t call = rr / rows, row = rr - call * rows;
         const int step = (int)(call >> 1);
         const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
         s1 += tab[2 * i] * v;
         s2 += tab[2 * i + 1] * v;
+        row += rpp;
+        while (row >= rows) {
+          row -= rows;
+          ++call;
+        }
       }
     }
     float* o = red + (size_t)(rl * nc4 + cl) * 12;
