@@ -313,13 +313,14 @@ def main():
     # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_cpu_baseline
-        sample_b = 256
+        sample_b = BATCH          # the whole per-GPU batch: ~0.5 s per call with a sane thread count
         cb = time_cpu_baseline(L, L, N_LF, EPS, BETA, sample_b, xp, vp, masks, budget_s=15.0)
         out["cpu_baseline"] = {"value": cb["value"], "unit": "chain-leapfrog-steps/s", "cores": cb["cores"],
                                "kind": "port",
                                "sample": f"{cb['calls']} timed apply_transition calls (both directions) on "
-                                         f"{sample_b} of the 2048 chains, same lattice/net/LF config, torch-CPU fp32, "
-                                         f"median {cb['seconds']:.3f} s per call"}
+                                         f"{sample_b} chains (the full per-GPU batch), same lattice/net/LF config, torch-CPU fp32, "
+                                         f"median {cb['seconds']:.3f} s per call; thread count probed for the best "
+                                         f"throughput ({cb['cores']} of {cb['cpus_available']} usable CPUs)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
