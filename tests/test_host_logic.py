@@ -273,3 +273,19 @@ def test_block_jackknife_and_run_statistics():
         np.testing.assert_allclose(stats.sem(actions), scipy_sem(actions))
     except ImportError:
         pass
+
+
+def test_cpu_baseline_uses_a_sane_thread_count():
+    """bench.py's cpu_baseline leg: threads are bounded by the CPUs this process may use (cgroup quota / affinity),
+    and torch's thread setting is restored afterwards."""
+    import torch
+    from oracle.cpu_baseline import effective_cpus, time_cpu_baseline
+    from tests import helpers as H
+    n = effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    xp, vp = H.gauge_weights(4, 4, regime="init")
+    masks = H.gauge_oracle(4, 4, 2, 0.2, xp, vp).mask
+    before = torch.get_num_threads()
+    r = time_cpu_baseline(4, 4, 2, 0.2, 2.0, 16, xp, vp, masks, budget_s=0.3)
+    assert torch.get_num_threads() == before
+    assert r["value"] > 0 and 1 <= r["cores"] <= r["cpus_available"] == n and r["calls"] >= 2
