@@ -1,7 +1,7 @@
 """End-to-end use of the library on the benchmark lattice: train the L2HMC sampler on 2D U(1) (8x8), then
 sample with the trained networks and compare the average plaquette with the exact infinite-volume value.
 
-    python examples/train_and_sample_u1.py [train_steps] [run_steps] [batch]
+    python examples/train_and_sample_u1.py [train_steps] [run_steps] [batch] [n_lf] [eps] [lr]
 
 Mirrors what `python gauge_model.py --train_steps ... --run_steps ...` does in the reference (training loop
 gauge_model.py:1119-1300, inference :1304-1460) without its file / plot side effects; everything between the
@@ -21,10 +21,13 @@ def main():
     train_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     run_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 512
-    L, beta, n_lf = 8, 2.0, 5
+    n_lf = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    eps0 = float(sys.argv[5]) if len(sys.argv) > 5 else 0.2
+    lr = float(sys.argv[6]) if len(sys.argv) > 6 else 1e-3
+    L, beta = 8, 2.0
     np.random.seed(42)
     lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=B, rand=True)
-    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.2, hmc=False, network_arch='generic', num_steps=n_lf,
+    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=eps0, hmc=False, network_arch='generic', num_steps=n_lf,
                            eps_trainable=True)
     sampler = la.GaugeSampler(dyn)
     x0 = torch.as_tensor(lat.samples.reshape(B, -1), dtype=torch.float32, device="cuda")
@@ -41,8 +44,9 @@ def main():
               f"tau_int(plaq) {tau[0]:.1f} steps  <Q^2> {sm.mean():.3f}  "
               f"tunnelling per step per chain {out['charge_diff'][therm:].mean():.4f}", flush=True)
 
+    print(f"8x8 U(1), beta {beta}, {B} chains, {n_lf} LF steps, eps0 {eps0}, lr {lr}", flush=True)
     report("untrained")
-    trainer = la.GaugeTrainer(dyn, lr_init=1e-3, lr_decay_steps=100, lr_decay_rate=0.96, clip_value=None)
+    trainer = la.GaugeTrainer(dyn, lr_init=lr, lr_decay_steps=100, lr_decay_rate=0.96, clip_value=None)
     t0 = time.perf_counter()
     hist = trainer.train(train_steps, samples_init=x0, beta_init=beta, beta_final=beta, print_steps=max(1, train_steps // 10))
     torch.cuda.synchronize()
