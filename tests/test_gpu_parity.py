@@ -781,3 +781,28 @@ def test_mcmc_step_is_hip_graph_capturable(la):
     g.replay()                                    # a second replay advances the chains from the first one's output
     torch.cuda.synchronize()
     assert not torch.equal(xg, eager) and float(xg.min()) >= 0.0
+
+
+def test_reference_quirk_wrap_breaks_torus_reversibility(la):
+    """Quirk Q10: the trajectory map is invertible (backward o forward = id), but the reference wraps the
+    state to [0, 2 pi) between steps and its networks act on raw angles, so the map does not commute with 2 pi
+    shifts: inverting from the WRAPPED image does not come back.  Reproduced, not 'fixed' (drop-in contract)."""
+    T = X = 8
+    B = 64
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, 5, 0.2, xp, vp)
+    dyn = H.gauge_hip(T, X, 5, 0.2, xp, vp, orc.mask, B)
+    x = torch.rand(B, 128, device="cuda") * (2 * np.pi)
+    v = torch.randn(B, 128, device="cuda")
+    x1, v1, _ = dyn.transition_kernel(x, 2.0, forward=True, momentum=v)
+    ang = lambda a, b: torch.remainder(a - b + np.pi, 2 * np.pi) - np.pi   # noqa: E731
+    x2, _, _ = dyn.transition_kernel(x1, 2.0, forward=False, momentum=v1)
+    assert float(ang(x2, x).abs().max()) < 1e-3
+    assert float((x1 < 0).float().mean() + (x1 >= 2 * np.pi).float().mean()) > 0.01      # some links left [0, 2 pi)
+    x3, _, _ = dyn.transition_kernel(torch.remainder(x1, 2 * np.pi), 2.0, forward=False, momentum=v1)
+    assert float(ang(x3, x).pow(2).mean().sqrt()) > 1e-2
+    # with no networks (plain HMC) the map is equivariant and the wrap is harmless
+    hmc = H.gauge_hip(T, X, 5, 0.2, xp, vp, orc.mask, B, hmc=True)
+    y1, w1, _ = hmc.transition_kernel(x, 2.0, forward=True, momentum=v)
+    y3, _, _ = hmc.transition_kernel(torch.remainder(y1, 2 * np.pi), 2.0, forward=False, momentum=w1)
+    assert float(ang(y3, x).abs().max()) < 1e-3
