@@ -13,11 +13,29 @@ from tests.test_gpu_train import _setup  # noqa: E402
 from l2hmc_amd.dist import shard_bounds  # noqa: E402
 
 
+def toy(out, B, rank, world):
+    """Same check for the toy-target trainer (DynamicsTrainer): sharded chains, two all-reduces."""
+    from tests.test_gpu_train import _small_setup
+    from l2hmc_amd.dynamics_trainer import DynamicsTrainer
+    tr, tm, x, z, dx, dz = _small_setup("mog", 50, 5, 0.1, B, "stress")
+    lo, hi = shard_bounds(B, world, rank)
+    tr = DynamicsTrainer(tr.dynamics, scale=0.1, dist=dist)
+    loss, *_ = tr.calc_loss_and_grads(x[lo:hi], z=z[lo:hi], draws_x=tuple(a[lo:hi] for a in dx),
+                                      draws_z=tuple(a[lo:hi] for a in dz))
+    if rank == 0:
+        np.savez(out, grads=tr.grads.cpu().numpy(), loss=float(loss))
+
+
 def main():
     out, B = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)            # the test box has one GPU: both ranks share it, gloo carries the exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 3 and sys.argv[3] == "toy":
+        toy(out, B, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     tr, tm, x, z, dx, dz = _setup(4, 2, 0.2, B, "mild")
     lo, hi = shard_bounds(B, world, rank)
     from l2hmc_amd.gauge_trainer import GaugeTrainer

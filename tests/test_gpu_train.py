@@ -490,3 +490,29 @@ def test_conv3d_gradients_generic_filter_count():
     want, _ = _ref_grads(tm, x, z, dx, dz, 2.5, 'cos_diff')
     assert abs(float(loss) - want) <= 2e-4 * max(1., abs(want))
     _compare(tr, tm)
+
+
+def test_toy_target_data_parallel_gradients_equal_full_batch(tmp_path):
+    """DynamicsTrainer over two ranks (one GPU, gloo): sharded chains give the full-batch loss and gradient."""
+    import socket
+    import subprocess
+    import sys
+    B = 12
+    tr, tm, x, z, dx, dz = _small_setup("mog", 50, 5, 0.1, B, "stress")
+    loss, *_ = tr.calc_loss_and_grads(x, z=z, draws_x=dx, draws_z=dz)
+    full = tr.grads.cpu().numpy().copy()
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    out = str(tmp_path / "dp_toy.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dp_train_worker.py"),
+                                       out, str(B), "toy"], env=env))
+    for p_ in procs:
+        assert p_.wait(timeout=300) == 0
+    with np.load(out) as f:
+        got, got_loss = f["grads"], float(f["loss"])
+    assert abs(got_loss - float(loss)) <= 1e-5 * max(1., abs(float(loss)))
+    assert np.abs(got - full).max() <= 2e-5 * np.abs(full).max()
