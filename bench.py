@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
+    ap.add_argument("--no-trained-ess", action="store_true",
+                    help="skip the 250-step training run + ESS/sec of the trained sampler (N = 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,7 +278,7 @@ def main():
                         "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
                 "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
                 "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss)}
-            if world == 1 and not args.no_cpu_baseline:
+            if world == 1 and not args.no_trained_ess:
                 # the secondary metric with TRAINED networks: a short training run (same shape), then ESS/sec of
                 # the sampler with the estimator used above (untrained networks barely move a chain)
                 try:
