@@ -227,6 +227,14 @@ size_t l2hmc_gauge_mcmc_step_ws_bytes(const l2hmc_gauge_plan* plan, int64_t B);
 int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, int64_t B, uint64_t seed,
                           uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
                           float* charge_diff, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+/* Same step, out of place (x_next may equal x_in) and with the per-step scalars the cross-shard reduce_mean of
+ * gauge_model.py:795 needs: step_sums (FOUR floats, or NULL) = [sum p_accept, sum |dQ|, B, scratch] -- the first
+ * three are what a rank all-reduces per accept/reject (fixed summation order; the fourth word is a ticket counter
+ * the kernels use to find the last workgroup). */
+int l2hmc_gauge_mcmc_step_ex(const l2hmc_gauge_plan* plan, float beta, const float* x_in, float* x_next, int64_t B,
+                             uint64_t seed, uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
+                             float* charge_diff, float* step_sums, void* ws, size_t ws_bytes,
+                             l2hmc_stream_t stream);
 
 /* Forward value of the training loss, per chain (gauge_model.py:766-795): terms[b] = std_loss + charge_loss;
  * the scalar loss is their mean over ALL chains of all ranks.  x, x_prop, z: [B][2*T*X]; px, pz: [B].

@@ -87,6 +87,8 @@ _PROTOS = {
     "l2hmc_gauge_mcmc_step_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
     "l2hmc_gauge_mcmc_step": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _U64, _U64, _P, _P, _P, _P, _P, _P,
                                         _SZ, _P]),
+    "l2hmc_gauge_mcmc_step_ex": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _I64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,
+                                           _SZ, _P]),
     "l2hmc_gauge_loss_terms": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F, _F, _F, _F, _P, _P]),
     "l2hmc_gauge_train_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
     "l2hmc_gauge_train_forward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ,

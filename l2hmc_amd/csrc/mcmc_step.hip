@@ -16,7 +16,9 @@ constexpr float kPiF = 3.14159265358979323846f;
 // elements [0, nV) are standard normals of stream (seed, 2*draw), elements of `cu` uniforms of stream
 // (seed, 2*draw+1): bit-identical to l2hmc_fill_normal / l2hmc_fill_uniform with those offsets.
 __global__ __launch_bounds__(256) void step_draws_kernel(float* __restrict__ V, int64_t nV, float* __restrict__ cu,
-                                                         int64_t ncu, uint64_t seed, uint64_t draw) {
+                                                         int64_t ncu, uint64_t seed, uint64_t draw,
+                                                         float* __restrict__ sums) {
+  if (sums && blockIdx.x == 0 && threadIdx.x == 0) sums[3] = 0.f;      // ticket counter of finish_step_kernel
   const int64_t nbV = (nV + 3) >> 2, nbU = (ncu + 3) >> 2;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbV + nbU;
        b += (int64_t)gridDim.x * blockDim.x) {
@@ -44,7 +46,9 @@ __global__ __launch_bounds__(256) void step_draws_kernel(float* __restrict__ V, 
 // D % 4 == 0.  Also writes coin | u (as step_draws_kernel) and dir[b].
 __global__ __launch_bounds__(256) void step_draws_selected_kernel(float* __restrict__ V, float* __restrict__ cu,
                                                                   int* __restrict__ dir, int64_t B, int D,
-                                                                  uint64_t seed, uint64_t draw) {
+                                                                  uint64_t seed, uint64_t draw,
+                                                                  float* __restrict__ sums) {
+  if (sums && blockIdx.x == 0 && threadIdx.x == 0) sums[3] = 0.f;
   const int d4n = D >> 2;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < B * d4n; w += (int64_t)gridDim.x * blockDim.x) {
@@ -79,7 +83,8 @@ __global__ __launch_bounds__(256) void step_draws_selected_kernel(float* __restr
 
 // sites % 64 == 0 and 256 % sites == 0.  Xw/Pw: rows [0,B) forward, [boff, boff+B) backward results
 // (boff = B; boff = 0 when only the selected direction was integrated into rows [0,B)).
-__global__ __launch_bounds__(256) void finish_step_kernel(float* __restrict__ x, const float* __restrict__ Xw,
+__global__ __launch_bounds__(256) void finish_step_kernel(const float* x, float* x_next, float* __restrict__ sums,
+                                                          float* __restrict__ part, const float* __restrict__ Xw,
                                                           const float* __restrict__ Pw, const float* __restrict__ cu,
                                                           int64_t B, int64_t boff, int T, int X, int cpw,
                                                           float* __restrict__ px,
@@ -150,13 +155,60 @@ __global__ __launch_bounds__(256) void finish_step_kernel(float* __restrict__ x,
     if (charges) charges[row] = ch * inv2pi;
     if (dq) dq[row] = fabsf(ch * inv2pi - cho * inv2pi);
   }
+  if (sums) {
+    // [sum p_accept, sum |dQ|, chains] for dist.StepStats, in a fixed order and without a further launch: every
+    // workgroup leaves its partial sums in `part`, the last one to arrive (ticket in sums[3]) adds them up
+    __shared__ float bs[2][4];
+    __shared__ float fin[2][256];
+    __shared__ int last;
+    if (site == 0) {
+      bs[0][c] = live ? p : 0.f;
+      bs[1][c] = live ? fabsf(ch * inv2pi - cho * inv2pi) : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int k = 0; k < cpw; ++k) {
+        a0 += bs[0][k];
+        a1 += bs[1][k];
+      }
+      part[2 * blockIdx.x] = a0;
+      part[2 * blockIdx.x + 1] = a1;
+      __threadfence();
+      last = atomicAdd(reinterpret_cast<int*>(sums + 3), 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      float a0 = 0.f, a1 = 0.f;
+      for (int b = tid; b < (int)gridDim.x; b += 256) {
+        a0 += part[2 * b];
+        a1 += part[2 * b + 1];
+      }
+      fin[0][tid] = a0;
+      fin[1][tid] = a1;
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+          fin[0][tid] += fin[0][tid + st];
+          fin[1][tid] += fin[1][tid + st];
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        sums[0] = fin[0][0];
+        sums[1] = fin[1][0];
+        sums[2] = (float)B;
+      }
+    }
+  }
   if (live) {
     float2 w;                                     // np.mod(x_out, 2 pi), gauge_model.py:1388
     w.x = fmodf(xo.x, kTwoPiF);
     w.y = fmodf(xo.y, kTwoPiF);
     if (w.x < 0.f) w.x += kTwoPiF;
     if (w.y < 0.f) w.y += kTwoPiF;
-    reinterpret_cast<float2*>(x)[row * sites + site] = w;
+    reinterpret_cast<float2*>(x_next)[row * sites + site] = w;
   }
 }
 
@@ -166,6 +218,29 @@ __global__ void charge_diff_kernel(const float* __restrict__ q_in, const float* 
   if (i >= B) return;
   if (charges) charges[i] = q_in[i];
   if (dq) dq[i] = fabsf(q_in[i] - q_out[i]);
+}
+
+// general path: [sum p, sum |dQ|, B] from the per-chain arrays, one workgroup, fixed order
+__global__ __launch_bounds__(256) void step_sums_kernel(const float* __restrict__ px, const float* __restrict__ dq,
+                                                        int64_t B, float* __restrict__ sums) {
+  __shared__ float red[2][4];
+  float a = 0.f, b = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += 256) {
+    a += px[i];
+    b += dq[i];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sums[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    sums[2] = (float)B;
+  }
 }
 
 }  // namespace l2hmc
@@ -186,9 +261,18 @@ extern "C" size_t l2hmc_gauge_mcmc_step_ws_bytes(const l2hmc_gauge_plan* plan, i
 extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, int64_t B, uint64_t seed,
                                      uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
                                      float* charge_diff, void* ws, size_t ws_bytes, l2hmc_stream_t stream) {
+  return l2hmc_gauge_mcmc_step_ex(plan, beta, x, x, B, seed, draw, px, actions, plaqs, charges, charge_diff, nullptr,
+                                  ws, ws_bytes, stream);
+}
+
+extern "C" int l2hmc_gauge_mcmc_step_ex(const l2hmc_gauge_plan* plan, float beta, const float* x_in, float* x_next,
+                                        int64_t B, uint64_t seed, uint64_t draw, float* px, float* actions,
+                                        float* plaqs, float* charges, float* charge_diff, float* step_sums, void* ws,
+                                        size_t ws_bytes, l2hmc_stream_t stream) {
   L2HMC_REQUIRE(plan != nullptr && B >= 0, "gauge_mcmc_step: bad arguments");
   if (B == 0) return L2HMC_OK;
-  L2HMC_REQUIRE(x && ws, "gauge_mcmc_step: NULL pointer");
+  L2HMC_REQUIRE(x_in && x_next && ws, "gauge_mcmc_step: NULL pointer");
+  const float* x = x_in;
   const size_t need = l2hmc_gauge_mcmc_step_ws_bytes(plan, B);
   if (ws_bytes < need) {
     set_error("gauge_mcmc_step: workspace %zu < %zu bytes", ws_bytes, need);
@@ -212,20 +296,20 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
     // half the rows: the momentum of the chosen direction only (same Philox streams), per-row direction from the coin
     int* dirs = reinterpret_cast<int*>(Pw + B);                     // second half of the [2B] accept buffer
     hipLaunchKernelGGL(step_draws_selected_kernel, dim3((unsigned)hmin(ceil_div(B * (D >> 2), 256), 4096)), dim3(256),
-                       0, s, Vw, cu, dirs, B, D, seed, draw);
+                       0, s, Vw, cu, dirs, B, D, seed, draw, step_sums);
     L2HMC_CHECK_LAUNCH("step_draws_selected");
     if (int e = launch_fused_trajectory(plan, beta, 0, plan->num_steps, x, Vw, dirs, B, Xw, Vw, nullptr, 0, Pw, s))
       return e;
     const int cpw = 256 / sites;
-    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, Xw, Pw, cu, B,
-                       (int64_t)0, T, X, cpw, px, actions, plaqs, charges, charge_diff);
+    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, x_next, step_sums, Vw,
+                       Xw, Pw, cu, B, (int64_t)0, T, X, cpw, px, actions, plaqs, charges, charge_diff);
     L2HMC_CHECK_LAUNCH("finish_step");
     return L2HMC_OK;
   }
   // momenta of both directions, coin | u  (tf.random_normal :269, tf.random_uniform :223,:246)
   const int64_t nblk = (((int64_t)2 * B * D + 3) >> 2) + ((2 * B + 3) >> 2);
   hipLaunchKernelGGL(step_draws_kernel, dim3((unsigned)hmin(ceil_div(nblk, 256), 4096)), dim3(256), 0, s, Vw,
-                     (int64_t)2 * B * D, cu, 2 * B, seed, draw);
+                     (int64_t)2 * B * D, cu, 2 * B, seed, draw, step_sums);
   L2HMC_CHECK_LAUNCH("step_draws");
 
   if (fused && fast_finish) {
@@ -233,8 +317,8 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
                                         s, /*x_mod=*/B, /*dir_split=*/B))
       return e;
     const int cpw = 256 / sites;
-    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, Xw, Pw, cu, B, B, T,
-                       X, cpw, px, actions, plaqs, charges, charge_diff);
+    hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)ceil_div(B, cpw)), dim3(256), 0, s, x, x_next, step_sums, Vw,
+                       Xw, Pw, cu, B, B, T, X, cpw, px, actions, plaqs, charges, charge_diff);
     L2HMC_CHECK_LAUNCH("finish_step");
     return L2HMC_OK;
   }
@@ -245,6 +329,7 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
   float* x_out = reinterpret_cast<float*>(rest + 2 * bd);
   rest += 3 * bd;
   rest_bytes -= 3 * bd;
+  L2HMC_REQUIRE(!step_sums || (px && charge_diff), "gauge_mcmc_step: step_sums needs px and charge_diff on this path");
   float* pp = px ? px : Xw;        // Xw / Pw of the head are free here: the transition carves its own copies
   if (int e = l2hmc_gauge_transition(plan, beta, x, Vw, Vw + (size_t)B * D, cu, cu + B, B, selected ? 0 : 1, x_prop,
                                      v_prop, pp,
@@ -257,5 +342,9 @@ extern "C" int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, f
   hipLaunchKernelGGL(charge_diff_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, s, q_in, q_out, B, charges,
                      charge_diff);
   L2HMC_CHECK_LAUNCH("charge_diff");
-  return l2hmc_wrap_angle(x_out, (int64_t)B * D, x, stream);
+  if (step_sums) {
+    hipLaunchKernelGGL(step_sums_kernel, dim3(1), dim3(256), 0, s, px, charge_diff, B, step_sums);
+    L2HMC_CHECK_LAUNCH("step_sums");
+  }
+  return l2hmc_wrap_angle(x_out, (int64_t)B * D, x_next, stream);
 }

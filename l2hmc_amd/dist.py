@@ -54,12 +54,33 @@ class StepStats:
         if len(self._pending) > 64:
             self._drain(keep=8)
 
+    def push_sums(self, buf):
+        """`buf` = device tensor [sum p_accept, sum |dQ|, n_chains] already produced by the step kernel
+        (l2hmc_gauge_mcmc_step_ex): nothing to compute here, only the asynchronous all-reduce when sharded."""
+        work = None
+        if self.dist is not None:
+            if self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side):
+                    work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+                buf.record_stream(self._side)
+            else:
+                work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((buf, work))
+        if len(self._pending) > 64:
+            self._drain(keep=8)
+
     def _drain(self, keep=0):
-        while len(self._pending) > keep:
-            buf, work = self._pending.pop(0)
+        """Fold all but the newest `keep` step buffers into the host total: one stacked sum and ONE device-to-host
+        copy per drain (not one per step)."""
+        n = len(self._pending) - keep
+        if n <= 0:
+            return
+        batch, self._pending = self._pending[:n], self._pending[n:]
+        for _, work in batch:
             if work is not None:
                 work.wait()
-            self.total += buf.detach().to("cpu", torch.float64)
+        self.total += torch.stack([b.detach() for b, _ in batch]).sum(dim=0, dtype=torch.float64).cpu()
 
     def wait(self):
         if self._side is not None:

@@ -41,18 +41,19 @@ class GaugeSampler:
         only in the direction its coin picks -- same random streams, same chains, half the work."""
         import ctypes as C
         dyn = self.dynamics
-        x_next = x.clone()
+        x_next = torch.empty_like(x)                       # written by the step (out of place: no copy of x)
         B = x.shape[0]
         outs = {k: torch.empty(B, dtype=torch.float32, device=x.device)
                 for k in ("px", "action", "avg_plaq", "top_charge", "dq")}
+        sums = torch.empty(4, dtype=torch.float32, device=x.device)     # [sum p, sum |dQ|, B, ticket], filled in-kernel
         plan, L = dyn._plan(), _lib.lib()
         ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
-        _lib.check(L.l2hmc_gauge_mcmc_step(
-            C.byref(plan), float(beta), x_next.data_ptr(), B, dyn._seed, self._step_count, outs["px"].data_ptr(),
-            outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(), outs["top_charge"].data_ptr(),
-            outs["dq"].data_ptr(), ws, nb, _lib.stream_ptr()))
+        _lib.check(L.l2hmc_gauge_mcmc_step_ex(
+            C.byref(plan), float(beta), _lib.dev_ptr(x, name="x"), x_next.data_ptr(), B, dyn._seed, self._step_count,
+            outs["px"].data_ptr(), outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(),
+            outs["top_charge"].data_ptr(), outs["dq"].data_ptr(), sums.data_ptr(), ws, nb, _lib.stream_ptr()))
         self._step_count += 1
-        self.stats.push(outs["px"], outs["dq"])
+        self.stats.push_sums(sums[:3])
         return x_next, outs["px"], outs, outs["dq"]
 
     def _step_composed(self, x, beta):
