@@ -26,6 +26,12 @@ vectors.  What *is* pinned against the reference's own known answers
   (v)   backward_lf o forward_lf == identity, sum-log-det == log|det J|,
         hmc=True degenerates to plain leapfrog gauge_dynamics.py:102-108,537-590
 
+Modules: ``lattice`` / ``nets`` / ``gauge_dynamics`` / ``dynamics`` / ``loss`` (NumPy, forward values),
+``torch_ref`` (the same graphs in float64 torch ops so that torch.autograd stands in for tf.gradients -- the
+checker for the training kernels; pinned to the NumPy modules, to finite differences and to the train_*.npz
+fixtures by tests/test_oracle_train.py), ``stats`` (lag-sum autocorrelations), ``cpu_baseline`` (torch-CPU
+fp32 op-for-op port, the timed baseline of bench.py).
+
 Every function cites the reference file:line it restates (paths relative to
 ``/root/reference``).
 """
