@@ -1,0 +1,46 @@
+"""One-off evidence (not a test): accept-rate parity over >= 1000 MCMC steps (north_star: +-1 %).  At every step
+the float64 oracle sees the device chain's state and the same draws, as in
+tests/test_gpu_parity.py::test_accept_rate_parity_on_identical_inputs, but for 1000 steps and two regimes.
+    python tools/check_accept_parity.py [steps] [chains]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import helpers as H  # noqa: E402
+
+
+def run(tag, N, eps, regime, steps, B):
+    T = X = 8
+    xp, vp = H.gauge_weights(T, X, regime=regime)
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 2 * np.pi, (B, 128)).astype(np.float32)
+    ph, po, ah, ao = [], [], [], []
+    t0 = time.time()
+    for it in range(steps):
+        v0f, v0b = rng.standard_normal((B, 128)), rng.standard_normal((B, 128))
+        coin, u = rng.uniform(size=B), rng.uniform(size=B)
+        got = dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+        want = orc.apply_transition(x.astype(np.float64), 2.0, v0f, v0b, coin, u)
+        p = got[2].cpu().numpy()
+        ph.append(p); po.append(want[2]); ah.append(p > u); ao.append(want[2] > u)
+        x = np.mod(got[3].cpu().numpy(), 2 * np.pi).astype(np.float32)
+        if it % 200 == 0:
+            print(f"  [{tag}] step {it} ({time.time() - t0:.0f} s)", flush=True)
+    ph, po = np.concatenate(ph), np.concatenate(po)
+    print(f"[{tag}: {N} LF, eps {eps}, '{regime}' weights, {steps} steps x {B} chains] mean accept probability "
+          f"HIP {ph.mean():.6f}  oracle {po.mean():.6f}  (diff {abs(ph.mean() - po.mean()):.2e}); accepted fraction "
+          f"HIP {np.mean(ah):.6f}  oracle {np.mean(ao):.6f}; max |p_hip - p_oracle| {np.abs(ph - po).max():.2e}; "
+          f"accept decisions that differ: {int(np.sum(np.concatenate(ah) != np.concatenate(ao)))} of {ph.size}",
+          flush=True)
+
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    run("moderate acceptance", 5, 0.08, "init", steps, B)
+    run("benchmark dynamics", 10, 0.25, "init", steps, B)
