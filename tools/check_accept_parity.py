@@ -39,8 +39,42 @@ def run(tag, N, eps, regime, steps, B):
           flush=True)
 
 
+def run_mog(steps, B):
+    """BASELINE.json configs[1]: mixture of Gaussians through `propose` (sampler.py:28-59), accept iff p - u >= 0."""
+    import l2hmc_amd as la
+    from oracle import dynamics as od
+    N, eps, nh = 10, 0.1, 50
+    tgt_o = H.mog_target_oracle()
+    tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    xp, vp = H.mlp_weights(2, nh, regime="init")
+    masks = od.make_masks(N, 2, np.random.RandomState(3))
+    orc = od.DynamicsOracle(2, tgt_o, N, eps, masks, xp, vp)
+    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=N, eps=eps,
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=nh))
+    dyn.set_masks(masks)
+    dyn.XNet.load_state(xp)
+    dyn.VNet.load_state(vp)
+    rng = np.random.default_rng(12)
+    x = tgt_o.get_samples(B, rng).astype(np.float32)
+    ph, po, flips = [], [], 0
+    for it in range(steps):
+        v0f, v0b = rng.standard_normal((B, 2)), rng.standard_normal((B, 2))
+        bits, u = rng.integers(0, 2, B).astype(np.float64), rng.uniform(size=B)
+        Lx, Lv, px, outs = la.propose(x, dyn, init_v=v0f, do_mh_step=True, init_v_backward=v0b, dir_bits=bits, u=u)
+        want = od.propose(x.astype(np.float64), orc, v0f, v0b, bits, u=u, do_mh_step=True)
+        p = px.cpu().numpy()
+        ph.append(p); po.append(want[2])
+        flips += int(np.sum(((p - u) >= 0) != ((want[2] - u) >= 0)))
+        x = outs[0].cpu().numpy()
+    ph, po = np.concatenate(ph), np.concatenate(po)
+    print(f"[MoG cfg 2: 10 LF, eps 0.1, H=50, {steps} steps x {B} chains] mean accept probability HIP {ph.mean():.6f}  "
+          f"oracle {po.mean():.6f}  (diff {abs(ph.mean() - po.mean()):.2e}); max |p_hip - p_oracle| "
+          f"{np.abs(ph - po).max():.2e}; accept decisions that differ: {flips} of {ph.size}", flush=True)
+
+
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     run("moderate acceptance", 5, 0.08, "init", steps, B)
     run("benchmark dynamics", 10, 0.25, "init", steps, B)
+    run_mog(steps, 64)
