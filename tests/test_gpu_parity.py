@@ -111,7 +111,8 @@ def test_golden_u1(la):
 
 # ----------------------------------------------------------------- dense S/T/Q net
 @pytest.mark.parametrize("regime", ["init", "stress"])
-@pytest.mark.parametrize("D,rows", [(128, 100), (128, 1), (32, 65), (512, 70)])
+@pytest.mark.parametrize("D,rows", [(128, 100), (128, 1), (32, 65), (512, 70),
+                                    (128, 16411)])      # >= 512 tiles of 128 x 128: the large-grid instantiation
 def test_stq_dense_matches_generic_net(la, regime, D, rows):
     rng = np.random.default_rng(5)
     p = onets.init_generic_net(np.random.default_rng(106), D, 4 * D, 2., **H.REGIMES[regime])
