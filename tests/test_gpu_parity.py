@@ -112,6 +112,7 @@ def test_golden_u1(la):
 # ----------------------------------------------------------------- dense S/T/Q net
 @pytest.mark.parametrize("regime", ["init", "stress"])
 @pytest.mark.parametrize("D,rows", [(128, 100), (128, 1), (32, 65), (512, 70),
+                                    (128, 5003),        # 64 x 128 tiles with 32-deep k-tiles (grid > 256 workgroups)
                                     (128, 16411)])      # >= 512 tiles of 128 x 128: the large-grid instantiation
 def test_stq_dense_matches_generic_net(la, regime, D, rows):
     rng = np.random.default_rng(5)
@@ -807,3 +808,39 @@ def test_reference_quirk_wrap_breaks_torus_reversibility(la):
     y1, w1, _ = hmc.transition_kernel(x, 2.0, forward=True, momentum=v)
     y3, _, _ = hmc.transition_kernel(torch.remainder(y1, 2 * np.pi), 2.0, forward=False, momentum=w1)
     assert float(ang(y3, x).abs().max()) < 1e-3
+
+
+def test_generic_dynamics_in_three_dimensions(la):
+    """x_dim = 3 runs the run-time-dimension instances of the toy-target kernels (x_dim 2 has compile-time ones):
+    trajectories, accept probabilities and `propose` against the float64 oracle."""
+    from oracle import dynamics as od
+    mus = [np.array([1., 0., 0.5]), np.array([0., 1., -0.5]), np.array([-1., -1., 0.])]
+    covs = [np.diag([0.05, 0.08, 0.1]), 0.07 * np.eye(3) + 0.02, np.diag([0.1, 0.05, 0.06])]
+    pis = [0.3, 0.5, 0.2]
+    tgt_o, tgt = od.GMM(mus, covs, pis), la.GMM(mus, covs, pis)
+    for nh in (50, 12):
+        N, eps, B = 4, 0.1, 33
+        xp, vp = H.mlp_weights(3, nh, regime="stress")
+        masks = od.make_masks(N, 3, np.random.RandomState(5))
+        orc = od.DynamicsOracle(3, tgt_o, N, eps, masks, xp, vp)
+        dyn = la.Dynamics(3, tgt.get_energy_function(), trajectory_length=N, eps=eps,
+                          net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=nh))
+        dyn.set_masks(masks)
+        dyn.XNet.load_state(xp)
+        dyn.VNet.load_state(vp)
+        rng = np.random.default_rng(8)
+        x = tgt_o.get_samples(B, rng)
+        v0f, v0b = rng.standard_normal((B, 3)), rng.standard_normal((B, 3))
+        bits, u = rng.integers(0, 2, B).astype(np.float64), rng.uniform(size=B)
+        assert H.relerr(np_(dyn.energy(x)), orc.energy(x.astype(np.float32).astype(np.float64))) < 2e-5
+        assert H.relerr(np_(dyn.grad_energy(x)), orc.grad_energy(x.astype(np.float32).astype(np.float64))) < TOL_OP
+        Xf, Vf, pf = dyn.forward(x, init_v=v0f)
+        Xb, Vb, pb = dyn.backward(x, init_v=v0b)
+        oXf, oVf, opf = orc.forward(x, v0f)
+        oXb, oVb, opb = orc.backward(x, v0b)
+        for got, want in ((Xf, oXf), (Vf, oVf), (Xb, oXb), (Vb, oVb)):
+            assert H.relerr(np_(got), want) < TOL_OP
+        assert np.abs(np_(pf) - opf).max() < TOL_P and np.abs(np_(pb) - opb).max() < TOL_P
+        Lx, Lv, px, outs = la.propose(x, dyn, init_v=v0f, do_mh_step=True, init_v_backward=v0b, dir_bits=bits, u=u)
+        want = od.propose(x, orc, v0f, v0b, bits, u=u, do_mh_step=True)
+        assert H.relerr(np_(Lx), want[0]) < TOL_OP and np.abs(np_(px) - want[2]).max() < TOL_P

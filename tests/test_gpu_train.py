@@ -312,15 +312,23 @@ def _small_setup(kind, H_nodes, N, eps, B, regime, seed=11, temperature=1.0):
     from l2hmc_amd.dynamics_trainer import DynamicsTrainer
     from oracle import dynamics as od
     from oracle.torch_ref import TorchDynamicsModel
+    dim = 2
     if kind == "mog":
         tgt_o = H.mog_target_oracle()
         tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    elif kind == "mog3":      # x_dim 3: the run-time-dimension instances of the kernels (x_dim 2 has its own)
+        dim = 3
+        mus = [np.array([1., 0., 0.5]), np.array([0., 1., -0.5]), np.array([-1., -1., 0.])]
+        covs = [np.diag([0.05, 0.08, 0.1]), 0.07 * np.eye(3) + 0.02, np.diag([0.1, 0.05, 0.06])]
+        pis = [0.3, 0.5, 0.2]
+        from oracle import dynamics as _od
+        tgt_o, tgt = _od.GMM(mus, covs, pis), la.GMM(mus, covs, pis)
     else:
         tgt_o = H.scg_target_oracle()
         tgt = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
-    xp, vp = H.mlp_weights(2, H_nodes, regime=regime)
-    masks = od.make_masks(N, 2, np.random.RandomState(3))
-    dyn = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=N, eps=eps,
+    xp, vp = H.mlp_weights(dim, H_nodes, regime=regime)
+    masks = od.make_masks(N, dim, np.random.RandomState(3))
+    dyn = la.Dynamics(dim, tgt.get_energy_function(), trajectory_length=N, eps=eps,
                       net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=H_nodes),
                       use_temperature=True)
     dyn.temperature = temperature
@@ -331,9 +339,9 @@ def _small_setup(kind, H_nodes, N, eps, B, regime, seed=11, temperature=1.0):
     tm = TorchDynamicsModel(tgt_o, N, eps, masks, xp, vp, temperature=temperature)
     rng = np.random.default_rng(seed)
     x = tgt_o.get_samples(B, rng)
-    z = rng.standard_normal((B, 2))
-    mk = lambda: (rng.standard_normal((B, 2)), rng.standard_normal((B, 2)), rng.integers(0, 2, B).astype(np.float64),  # noqa: E731
-                  rng.uniform(size=B))
+    z = rng.standard_normal((B, dim))
+    mk = lambda: (rng.standard_normal((B, dim)), rng.standard_normal((B, dim)),   # noqa: E731
+                  rng.integers(0, 2, B).astype(np.float64), rng.uniform(size=B))
     return tr, tm, x, z, mk(), mk()
 
 
@@ -352,6 +360,8 @@ def _mlp_packed_ref(net):
     ("mog", 50, 5, 0.1, 37, "stress", 1.0),        # cfg 2 widths, ragged batch (3 workgroups, one partly empty)
     ("mog", 50, 10, 0.1, 16, "mild", 2.5),         # full trajectory length, tempered target
     ("scg", 10, 5, 0.1, 21, "stress", 1.0),        # cfg 1: 16-wide kernel variant, Gaussian target
+    ("mog3", 50, 4, 0.1, 19, "stress", 1.0),       # x_dim 3, three components: run-time-dimension instance, H = 50
+    ("mog3", 12, 3, 0.1, 9, "mild", 1.5),          # ... and its 16-wide variant
 ])
 def test_toy_target_loss_gradients_match_autograd(kind, H_nodes, N, eps, B, regime, temp):
     tr, tm, x, z, dx, dz = _small_setup(kind, H_nodes, N, eps, B, regime, temperature=temp)
