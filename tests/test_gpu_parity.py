@@ -844,3 +844,28 @@ def test_generic_dynamics_in_three_dimensions(la):
         Lx, Lv, px, outs = la.propose(x, dyn, init_v=v0f, do_mh_step=True, init_v_backward=v0b, dir_bits=bits, u=u)
         want = od.propose(x, orc, v0f, v0b, bits, u=u, do_mh_step=True)
         assert H.relerr(np_(Lx), want[0]) < TOL_OP and np.abs(np_(px) - want[2]).max() < TOL_P
+
+
+@pytest.mark.parametrize("T,X", [(4, 16), (16, 4), (2, 32)])
+def test_fused_kernel_on_non_square_lattices(la, T, X):
+    """D = 2*T*X = 128 selects the whole-trajectory kernel for any T x X = 64 (its plaquette stencil indexes sites with
+    shifts: X is a power of two); non-square extents against the float64 oracle, and against the layered path."""
+    N, eps, beta, B = 3, 0.15, 2.0, 21
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, 128)
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    got = {}
+    for fused in (True, False):
+        dyn.fused = fused
+        got[fused] = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+        assert H.relerr(np_(got[fused][0]), want[0]) < 5 * TOL_OP and H.relerr(np_(got[fused][1]), want[1]) < 5 * TOL_OP
+        assert np.abs(np_(got[fused][2]) - want[2]).max() < TOL_P
+    assert H.relerr(np_(got[True][0]), np_(got[False][0])) < 5 * TOL_OP
+    # and the native step (finish kernel indexes the same lattice)
+    smp = la.GaugeSampler(dyn)
+    xs = torch.as_tensor(x, dtype=torch.float32, device="cuda")
+    xn, px, obs, dq = smp.step(xs, beta)
+    assert H.relerr(np_(obs["action"]), olat.total_action(x.astype(np.float32).astype(np.float64), T, X)) < TOL_OP
+    assert H.relerr(np_(obs["top_charge"]), olat.top_charge(x.astype(np.float32).astype(np.float64), T, X)) < 1e-4
