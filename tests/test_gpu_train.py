@@ -560,3 +560,22 @@ def test_large_batch_layered_gradients_equal_fused_gradients():
             assert float((a - b).norm()) <= 1e-4 * float(b.norm()), (net, k)
             assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), (net, k)
     assert abs(float(res[True][1]["eps"][0]) - float(res[False][1]["eps"][0])) <= 1e-4 * abs(float(res[False][1]["eps"][0]))
+
+
+def test_loss_gradients_on_a_non_square_lattice():
+    """4 x 16 (D = 128): the fused taped forward / reverse kernels with T != X, against float64 autograd."""
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    T, X, N, eps, B = 4, 16, 2, 0.1, 11
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    tr = GaugeTrainer(dyn)
+    tm = TorchGaugeModel(T, X, N, eps, orc.mask, xp, vp)
+    rng = np.random.default_rng(7)
+    x, z = rng.uniform(0, 2 * np.pi, (B, 128)), rng.standard_normal((B, 128))
+    mk = lambda: (rng.standard_normal((B, 128)), rng.standard_normal((B, 128)), rng.uniform(size=B), rng.uniform(size=B))  # noqa: E731
+    dx, dz = mk(), mk()
+    loss, *_ = tr.calc_loss_and_grads(x, 2.5, z=z, draws_x=dx, draws_z=dz)
+    want, _ = _ref_grads(tm, x, z, dx, dz, 2.5, 'cos_diff')
+    assert abs(float(loss) - want) <= 2e-4 * max(1., abs(want))
+    _compare(tr, tm)
