@@ -10,7 +10,9 @@ wrap to [0, 2pi) and per-step observables -- all resident in HBM.  Workload:
 BASELINE.json configs[2], the configuration its metric is quoted on (2D U(1)
 8x8, beta 2.0, batch 2048 per GPU, 10 leapfrog steps, GenericNet H=512, fp32).
 
-N > 1 (launched through torch.distributed.run, one rank per GPU): chains are
+N > 1: a bare `python bench.py --gpus N` starts its own N ranks (child processes through
+torch.distributed.run, before this process touches the GPU); under torch.distributed.run (WORLD_SIZE set) the
+process is a rank.  One rank per GPU: chains are
 independent, so every rank integrates its own 2048 chains (weak scaling) and
 the only exchange is one small RCCL all-reduce of the per-step scalar sums
 (accept probability, |dQ|, count), issued on a side stream.
@@ -23,6 +25,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,6 +60,55 @@ def build_dynamics(batch, both_directions=True, arch='generic'):
     return dyn, xp, vp, dyn.mask.cpu().numpy()
 
 
+def launch_command(gpus, env, argv, port=None):
+    """The decision the driver's bare `python bench.py --gpus N` needs (gauge_model.py:2041 relies on mpirun to
+    start the ranks; here the script starts its own): None when this process IS a rank (WORLD_SIZE is set by
+    torch.distributed.run) or when N == 1; otherwise the command that starts N fresh ranks of this script,
+    one per GPU, rendezvous on 127.0.0.1."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(cmd):
+    """Parent of the ranks: never touches the GPU (no HIP call has been made in this process), starts the ranks
+    as CHILD processes (no exec), relays their output -- rank 0 prints the JSON line -- and returns the launcher's
+    exit code, non-zero if any rank failed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(world, rank):
+    """The cross-rank plumbing of the timed region without the GPU work (CPU test hook): barrier on both sides,
+    MAX over ranks of the elapsed time, rank 0 prints one line."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": int(ranks.item()),
+                          "max_elapsed_s": float(t.item())}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,11 +122,23 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
     ap.add_argument("--no-trained-ess", action="store_true",
                     help="skip the 250-step training run + ESS/sec of the trained sampler (N = 1 only)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="test hook (CPU, gloo): start the ranks, barrier, max-over-ranks reduction, print "
+                         "{'rendezvous_only': true, ...} and exit -- no measurement, no GPU")
     args = ap.parse_args()
+
+    cmd = launch_command(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:                           # before anything initialises the GPU in this process
+        raise SystemExit(self_launch(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py "
+                         f"--gpus N` or through torch.distributed.run with --nproc-per-node N)")
+    if args.rendezvous_only:
+        raise SystemExit(rendezvous_only(world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0 over gloo.
@@ -89,7 +154,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from l2hmc_amd import _lib, GaugeSampler, stats as chain_stats
     dev = torch.device("cuda", local_rank)

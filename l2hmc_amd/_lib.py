@@ -167,8 +167,27 @@ def dev_ptr(t, dtype=torch.float32, name="tensor"):
     return t.data_ptr()
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (default: the current device).  Kernels are launched
+    on the CURRENT device, so a tensor living elsewhere is an error, not a silent cross-device launch."""
+    if device is not None:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the HIP path has no CPU fallback")
+        idx = torch.cuda.current_device() if device.index is None else device.index
+        if idx != torch.cuda.current_device():
+            raise RuntimeError(f"object lives on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}; "
+                               f"wrap the call in `with torch.cuda.device({idx}):`")
+        return torch.cuda.current_stream(idx).cuda_stream
     return torch.cuda.current_stream().cuda_stream
+
+
+def step_draw_index(draws):
+    """The native MCMC step (l2hmc_gauge_mcmc_step) consumes the Philox stream pair (2d, 2d+1) of its `draw`
+    argument; `GaugeDynamics._normal/_uniform` consume stream `_draws` and advance it by one.  ONE counter serves
+    both: the step takes the next even-aligned pair at or after `draws`.  Returns (d, new_draws)."""
+    d = (int(draws) + 1) // 2
+    return d, 2 * d + 2
 
 
 def as_dev(a, device=None, dtype=torch.float32):

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/l2hmc_hip.h"
 
@@ -34,6 +35,30 @@ static inline int hmax(int a, int b) { return a > b ? a : b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 constexpr int kWave = 64;  // CDNA wavefront
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: a launch site keeps one
+// of these and repeats the opt-in the first time it runs on each device (bit per ordinal; a race between two
+// threads repeats an idempotent call, nothing worse).
+class DeviceOnce {
+  std::atomic<uint64_t> mask_[4] = {};      // 256 device ordinals
+  static bool slot(int* word, uint64_t* bit) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return false;
+    *word = d >> 6;
+    *bit = 1ull << (d & 63);
+    return true;
+  }
+ public:
+  bool pending() const {                     // true: the opt-in has not been made on this device yet
+    int w; uint64_t b;
+    if (!slot(&w, &b)) return true;
+    return (mask_[w].load(std::memory_order_acquire) & b) == 0;
+  }
+  void done() {
+    int w; uint64_t b;
+    if (slot(&w, &b)) mask_[w].fetch_or(b, std::memory_order_release);
+  }
+};
 
 // Optional per-kernel-class timing with HIP events on the launch stream
 // (l2hmc_profile_begin/_end; used by bench.py's roofline pass, off otherwise).

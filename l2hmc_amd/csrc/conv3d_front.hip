@@ -157,15 +157,15 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                                       (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<8, 8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<16, 16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<0, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.done();
   }
   if (a.F == 8 && a.T == 8 && a.X == 8)
     hipLaunchKernelGGL((conv3d_front_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
@@ -444,15 +444,15 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
                      align_up(cells1, 1) + align_up(cells2, 16) + 16;
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<8, 8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<16, 16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<0, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.done();
   }
   if (a.F == 8 && a.T == 8 && a.X == 8)
     hipLaunchKernelGGL((conv3d_front_bwd_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);

@@ -444,15 +444,15 @@ int launch_fused_train_backward(const l2hmc_gauge_plan* p, float beta, const int
                                 float* const coef_parts[4], float* deps_part, hipStream_t stream) {
   using Cfg = FusedBwdCfg<128, 512>;
   L2HMC_REQUIRE(fused_train_supported(p), "fused training backward: unsupported plan");
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
-  if (!attr_set) {
+  if (attr_once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_train_bwd_fused_kernel<128, 512>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("fused training backward: cannot reserve %zu B of LDS", lds);
       return L2HMC_ERR_HIP;
     }
-    attr_set = true;
+    attr_once.done();
   }
   hipLaunchKernelGGL(pack_fused_bwd_kernel, dim3(1024), dim3(256), 0, stream, p->xnet, pack_x);
   hipLaunchKernelGGL(pack_fused_bwd_kernel, dim3(1024), dim3(256), 0, stream, p->vnet, pack_v);

@@ -710,9 +710,9 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   using CfgG = FusedCfg<128, 512, 128, false>;
   using CfgC = FusedCfg<128, 256, 64, true>;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : CfgG::LDS_FLOATS);
-  if (!attr_set) {
+  if (attr_once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
@@ -722,7 +722,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
       set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
       return L2HMC_ERR_HIP;
     }
-    attr_set = true;
+    attr_once.done();
   }
   FusedArgs a{};
   a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = step_begin; a.step_end = step_end;
@@ -740,8 +740,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
                   "fused trajectory: NULL tape pointer");
     a.tx = *tape_x;
     a.tv = *tape_v;
-    static bool tape_attr = false;
-    if (!tape_attr) {
+    static DeviceOnce tape_once;
+    if (tape_once.pending()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
@@ -751,7 +751,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
         set_error("fused trajectory: cannot reserve %zu B of LDS", lds);
         return L2HMC_ERR_HIP;
       }
-      tape_attr = true;
+      tape_once.done();
     }
   }
 #ifdef L2HMC_STAMPS

@@ -3,7 +3,7 @@
 // `_calc_top_charges_diff(fft=True)` (:701-725).  One workgroup per chain; the three plaquette stencils
 // (x, x_, z) and the two metric sums are reduced by fixed shuffle trees.  As in the reference, both
 // auxiliary terms compare z with the proposal of x (x_), quirk Q9.
-// This is the first piece of SURVEY.md 8f/f1; the backward pass is not built yet.
+// The derivative of this loss through both accept probabilities is `loss_bwd_kernel` in train.hip.
 #include "common.h"
 
 namespace l2hmc {

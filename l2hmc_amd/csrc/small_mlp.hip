@@ -212,8 +212,8 @@ extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float*
                                       (size_t)HP * (kSmallThreads / kLPC));
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
   const dim3 grid((unsigned)ceil_div(rows, kSmallThreads / kLPC));
-  static bool attr_set = false;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
+  if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, 2>),
@@ -222,7 +222,7 @@ extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float*
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.done();
   }
   const dim3 blk(kSmallThreads);
   hipStream_t st = (hipStream_t)stream;

@@ -735,8 +735,8 @@ extern "C" int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float*
                         : (HP == 16 ? small_train_lds<16, kMaxDim>(dim, plan->target.K, N)
                                     : small_train_lds<64, kMaxDim>(dim, plan->target.K, N));
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_train_step: LDS image %zu B too large (trajectory too long?)", lds);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, 2>),
@@ -745,7 +745,7 @@ extern "C" int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float*
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.done();
   }
   hipStream_t s = (hipStream_t)stream;
   const int nwg = (int)ceil_div(rows, kSlots);

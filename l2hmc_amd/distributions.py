@@ -36,7 +36,7 @@ class _PackedTarget:
         g = torch.empty_like(x) if want_grad else None
         st = self.struct(temperature)
         _lib.check(_lib.lib().l2hmc_mog_energy_grad(C.byref(st), x.data_ptr(), x.shape[0], e.data_ptr(),
-                                                    None if g is None else g.data_ptr(), _lib.stream_ptr()))
+                                                    None if g is None else g.data_ptr(), _lib.stream_ptr(x.device)))
         return e, g
 
 

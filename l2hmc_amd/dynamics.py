@@ -74,7 +74,7 @@ class Dynamics(object):
         v = _lib.as_dev(v, self._device)
         out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
         _lib.check(_lib.lib().l2hmc_kinetic_energy(v.data_ptr(), v.shape[0], v.shape[1], out.data_ptr(),
-                                                   _lib.stream_ptr()))
+                                                   _lib.stream_ptr(self._device)))
         return out
 
     def energy(self, x, aux=None):
@@ -100,7 +100,7 @@ class Dynamics(object):
     def _normal(self, shape):
         out = torch.empty(shape, dtype=torch.float32, device=self._device)
         _lib.check(_lib.lib().l2hmc_fill_normal(out.data_ptr(), out.numel(), self._seed, self._draws,
-                                                _lib.stream_ptr()))
+                                                _lib.stream_ptr(self._device)))
         self._draws += 1
         return out
 
@@ -115,7 +115,7 @@ class Dynamics(object):
         plan = self._plan()
         _lib.check(_lib.lib().l2hmc_small_trajectory(
             C.byref(plan), x.data_ptr(), _lib.dev_ptr(v, name="init_v"), _lib.dev_ptr(dirs, torch.int32), rows,
-            X.data_ptr(), V.data_ptr(), lj.data_ptr(), p.data_ptr(), _lib.stream_ptr()))
+            X.data_ptr(), V.data_ptr(), lj.data_ptr(), p.data_ptr(), _lib.stream_ptr(self._device)))
         return (X, V, lj) if log_jac else (X, V, p)
 
     def both(self, x, init_v_forward=None, init_v_backward=None, log_jac=False):
@@ -134,7 +134,7 @@ class Dynamics(object):
         plan = self._plan()
         _lib.check(_lib.lib().l2hmc_small_trajectory(
             C.byref(plan), xx.data_ptr(), vv.data_ptr(), dirs.data_ptr(), 2 * B, X.data_ptr(), V.data_ptr(),
-            lj.data_ptr(), p.data_ptr(), _lib.stream_ptr()))
+            lj.data_ptr(), p.data_ptr(), _lib.stream_ptr(self._device)))
         third = lj if log_jac else p
         return (X[:B], V[:B], third[:B]), (X[B:], V[B:], third[B:])
 
@@ -156,5 +156,5 @@ class Dynamics(object):
         lj = _lib.as_dev(log_jac, self._device)
         p = torch.empty_like(e_old)
         _lib.check(_lib.lib().l2hmc_accept_prob(e_old.data_ptr(), e_new.data_ptr(), lj.data_ptr(), p.numel(),
-                                                p.data_ptr(), _lib.stream_ptr()))
+                                                p.data_ptr(), _lib.stream_ptr(self._device)))
         return p

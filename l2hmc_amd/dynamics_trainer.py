@@ -56,7 +56,7 @@ class DynamicsTrainer:
 
         def uniform(n):
             out = torch.empty(n, dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), n, dyn._seed, dyn._draws, _lib.stream_ptr()))
+            _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), n, dyn._seed, dyn._draws, _lib.stream_ptr(self.dynamics._device)))
             dyn._draws += 1
             return out
 
@@ -77,7 +77,7 @@ class DynamicsTrainer:
         ws, nb = self._ws.get(L.l2hmc_small_train_ws_bytes(C.byref(plan), R), dev)
         _lib.check(L.l2hmc_small_train_step(C.byref(plan), x0.data_ptr(), v0.data_ptr(), dirs.data_ptr(), R, self.scale,
                                             1.0 / (B * self.world), xN.data_ptr(), vN.data_ptr(), p.data_ptr(),
-                                            terms.data_ptr(), self.grads.data_ptr(), ws, nb, _lib.stream_ptr()))
+                                            terms.data_ptr(), self.grads.data_ptr(), ws, nb, _lib.stream_ptr(self.dynamics._device)))
         self.grads[-1] *= float(dyn.eps)              # d/d alpha = eps * d/d eps  (utils/dynamics.py:51-60)
         buf = torch.stack([terms.sum(dtype=torch.float32), torch.full((), float(B), dtype=torch.float32, device=dev)])
         if self.dist is not None:
@@ -90,7 +90,7 @@ class DynamicsTrainer:
         return loss, x_out, px
 
     def apply_gradients(self):
-        dyn, L, s = self.dynamics, _lib.lib(), _lib.stream_ptr()
+        dyn, L, s = self.dynamics, _lib.lib(), _lib.stream_ptr(self.dynamics._device)
         lr = self.learning_rate()
         self._adam_t += 1
         t = self._adam_t

@@ -149,14 +149,14 @@ class GaugeDynamics:
     def _normal(self, shape):
         out = torch.empty(shape, dtype=torch.float32, device=self._device)
         _lib.check(_lib.lib().l2hmc_fill_normal(out.data_ptr(), out.numel(), self._seed, self._draws,
-                                                _lib.stream_ptr()))
+                                                _lib.stream_ptr(self._device)))
         self._draws += 1
         return out
 
     def _uniform(self, shape):
         out = torch.empty(shape, dtype=torch.float32, device=self._device)
         _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), out.numel(), self._seed, self._draws,
-                                                 _lib.stream_ptr()))
+                                                 _lib.stream_ptr(self._device)))
         self._draws += 1
         return out
 
@@ -186,7 +186,7 @@ class GaugeDynamics:
             C.byref(plan), float(beta), _lib.dev_ptr(x, name="position"), _lib.dev_ptr(v0f, name="momentum_f"),
             _lib.dev_ptr(v0b, name="momentum_b"), _lib.dev_ptr(coin, name="coin"), _lib.dev_ptr(u, name="u"),
             B, both, x_prop.data_ptr(), v_prop.data_ptr(), p.data_ptr(), x_out.data_ptr(), ws, nb,
-            _lib.stream_ptr()))
+            _lib.stream_ptr(self._device)))
         if self.check_numerics and not bool(torch.isfinite(x_prop).all() & torch.isfinite(v_prop).all()):
             # the reference wraps every exp of the sub-updates in tf.check_numerics and aborts the step;
             # the kernels propagate NaN / inf instead, and this opt-in check (one host sync) reports it
@@ -207,7 +207,7 @@ class GaugeDynamics:
         _lib.check(L.l2hmc_gauge_trajectory(
             C.byref(plan), float(beta), _lib.dev_ptr(x, name="position"), _lib.dev_ptr(v0, name="momentum"),
             _lib.dev_ptr(dirs, torch.int32), rows, x_out.data_ptr(), v_out.data_ptr(), sld.data_ptr(),
-            p.data_ptr(), ws, nb, _lib.stream_ptr()))
+            p.data_ptr(), ws, nb, _lib.stream_ptr(self._device)))
         if return_logdet:
             return x_out, v_out, p, sld
         return x_out, v_out, p
@@ -221,7 +221,7 @@ class GaugeDynamics:
         ws, nb = self._ws.get(L.l2hmc_gauge_ws_bytes(C.byref(plan), rows), x.device)
         _lib.check(L.l2hmc_gauge_leapfrog(C.byref(plan), float(beta), int(step), x.data_ptr(), v.data_ptr(),
                                           _lib.dev_ptr(dirs, torch.int32), rows, logdet.data_ptr(), ws, nb,
-                                          _lib.stream_ptr()))
+                                          _lib.stream_ptr(self._device)))
         return x, v, logdet
 
     def _forward_lf(self, position, momentum, beta, step):
@@ -245,7 +245,7 @@ class GaugeDynamics:
         _lib.check(_lib.lib().l2hmc_lf_update_v(
             v.data_ptr(), grad.data_ptr(), _lib.dev_ptr(self._x(S)), _lib.dev_ptr(self._x(T)),
             _lib.dev_ptr(self._x(Q)), float(self.eps), int(backward), x.shape[0], x.shape[1],
-            v_out.data_ptr(), logdet.data_ptr(), _lib.stream_ptr()))
+            v_out.data_ptr(), logdet.data_ptr(), _lib.stream_ptr(self._device)))
         return v_out, logdet
 
     def _update_momentum_forward(self, position, momentum, beta, t):
@@ -265,7 +265,7 @@ class GaugeDynamics:
         _lib.check(_lib.lib().l2hmc_lf_update_x(
             x.data_ptr(), v.data_ptr(), keep.data_ptr(), _lib.dev_ptr(self._x(S)), _lib.dev_ptr(self._x(T)),
             _lib.dev_ptr(self._x(Q)), float(self.eps), int(backward), x.shape[0], x.shape[1],
-            x_out.data_ptr(), logdet.data_ptr(), _lib.stream_ptr()))
+            x_out.data_ptr(), logdet.data_ptr(), _lib.stream_ptr(self._device)))
         return x_out, logdet
 
     def _update_position_forward(self, position, momentum, t, mask, mask_inv):
@@ -283,7 +283,7 @@ class GaugeDynamics:
         sld = _lib.as_dev(sumlogdet, self._device)
         p = torch.empty_like(old)
         _lib.check(_lib.lib().l2hmc_accept_prob(old.data_ptr(), new.data_ptr(), sld.data_ptr(), old.numel(),
-                                                p.data_ptr(), _lib.stream_ptr()))
+                                                p.data_ptr(), _lib.stream_ptr(self._device)))
         return p
 
     def _get_time(self, i):
@@ -309,7 +309,7 @@ class GaugeDynamics:
         v = self._x(v)
         out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
         _lib.check(_lib.lib().l2hmc_kinetic_energy(v.data_ptr(), v.shape[0], v.shape[1], out.data_ptr(),
-                                                   _lib.stream_ptr()))
+                                                   _lib.stream_ptr(self._device)))
         return out
 
     def hamiltonian(self, position, momentum, beta):

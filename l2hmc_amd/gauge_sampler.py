@@ -19,7 +19,6 @@ class GaugeSampler:
         self.lattice = dynamics.lattice
         self.beta_init, self.beta_final, self.train_steps = beta_init, beta_final, train_steps
         self.stats = StepStats(dynamics._device, dist)
-        self._step_count = 0
 
     def update_beta(self, step):
         """gauge_model.py:1039-1046: linear annealing of 1/beta."""
@@ -29,7 +28,7 @@ class GaugeSampler:
 
     def wrap(self, x):
         out = torch.empty_like(x)
-        _lib.check(_lib.lib().l2hmc_wrap_angle(x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream_ptr()))
+        _lib.check(_lib.lib().l2hmc_wrap_angle(x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream_ptr(self.dynamics._device)))
         return out
 
     def step(self, x, beta):
@@ -48,11 +47,14 @@ class GaugeSampler:
         sums = torch.empty(4, dtype=torch.float32, device=x.device)     # [sum p, sum |dQ|, B, ticket], filled in-kernel
         plan, L = dyn._plan(), _lib.lib()
         ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
+        # the step's random streams come from the dynamics' own draw counter (saved / restored with the state):
+        # a sampler never replays noise the dynamics, a trainer or another sampler on the same dynamics used
+        draw, dyn._draws = _lib.step_draw_index(dyn._draws)
         _lib.check(L.l2hmc_gauge_mcmc_step_ex(
-            C.byref(plan), float(beta), _lib.dev_ptr(x, name="x"), x_next.data_ptr(), B, dyn._seed, self._step_count,
+            C.byref(plan), float(beta), _lib.dev_ptr(x, name="x"), x_next.data_ptr(), B, dyn._seed, draw,
             outs["px"].data_ptr(), outs["action"].data_ptr(), outs["avg_plaq"].data_ptr(),
-            outs["top_charge"].data_ptr(), outs["dq"].data_ptr(), sums.data_ptr(), ws, nb, _lib.stream_ptr()))
-        self._step_count += 1
+            outs["top_charge"].data_ptr(), outs["dq"].data_ptr(), sums.data_ptr(), ws, nb,
+            _lib.stream_ptr(dyn._device)))
         self.stats.push_sums(sums[:3])
         return x_next, outs["px"], outs, outs["dq"]
 
@@ -85,7 +87,7 @@ class GaugeSampler:
             x.data_ptr(), x_prop.data_ptr(), px.data_ptr(), z.data_ptr(), pz.data_ptr(), x.shape[0], T, X,
             self.METRICS[metric], float(loss_scale), float(weights.get('aux_weight', 1.)),
             float(weights.get('std_weight', 1.)), float(weights.get('charge_weight', 1.)), terms.data_ptr(),
-            _lib.stream_ptr()))
+            _lib.stream_ptr(self.dynamics._device)))
         buf = torch.stack([terms.sum(dtype=torch.float32),
                            torch.full((), float(terms.numel()), dtype=torch.float32, device=x.device)])
         if self.stats.dist is not None:

@@ -26,7 +26,7 @@ METRICS = {'l1': 0, 'l2': 1, 'cos': 2, 'cos2': 3, 'cos_diff': 4}
 class GaugeTrainer:
     def __init__(self, dynamics, lr_init=1e-3, lr_decay_steps=1000, lr_decay_rate=0.96, clip_value=None,
                  metric='cos_diff', loss_scale=1., aux_weight=1., std_weight=1., charge_weight=1., dist=None,
-                 allreduce_grads=True, beta1=0.9, beta2=0.999, epsilon=1e-8):
+                 allreduce_grads=True, beta1=0.9, beta2=0.999, epsilon=1e-8, eager_variables=False):
         if metric not in METRICS:        # gauge_model.py:653-655
             raise AttributeError(f"metric={metric}. Expected one of: 'l1', 'l2', 'cos', 'cos2', or 'cos_diff'.")
         if dynamics.hmc:
@@ -44,6 +44,12 @@ class GaugeTrainer:
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist is not None else 1
         self.allreduce_grads = bool(allreduce_grads)
+        # Which variable list the optimiser sees.  Graph mode -- the path the CLI runs -- differentiates and
+        # applies over `dynamics.variables` (gauge_model.py:825, :965-968), which holds the step size even when
+        # it was created with trainable=False (gauge_dynamics.py:91-96): eps moves and counts in the clip norm
+        # REGARDLESS of `eps_trainable`.  Eager mode uses `trainable_variables` (:820) and respects the flag.
+        # Default = graph mode, as the reference's sessions run; eager_variables=True = the eager branch.
+        self.eager_variables = bool(eager_variables)
         self.global_step = 0
         dev = dyn._device
         self._nets = (dyn.position_fn, dyn.momentum_fn)
@@ -122,7 +128,7 @@ class GaugeTrainer:
         sld, p = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(2))
         plan, L = dyn._plan(), _lib.lib()
         ws, nb = self._ws.get(L.l2hmc_gauge_train_ws_bytes(C.byref(plan), R), dev)
-        s = _lib.stream_ptr()
+        s = _lib.stream_ptr(self.dynamics._device)
         _lib.check(L.l2hmc_gauge_train_forward(C.byref(plan), float(beta), x0.data_ptr(), v0.data_ptr(),
                                                dirs.data_ptr(), R, xN.data_ptr(), vN.data_ptr(), sld.data_ptr(),
                                                p.data_ptr(), ws, nb, s))
@@ -161,7 +167,7 @@ class GaugeTrainer:
     # ---- optimiser --------------------------------------------------------------
     def apply_gradients(self):
         """clip_by_global_norm (if clip_value) + Adam on [xnet | vnet | eps]; bumps global_step."""
-        dyn, L, s = self.dynamics, _lib.lib(), _lib.stream_ptr()
+        dyn, L, s = self.dynamics, _lib.lib(), _lib.stream_ptr(self.dynamics._device)
         lr = self.learning_rate()
         self._adam_t = getattr(self, "_adam_t", 0) + 1
         t = self._adam_t
@@ -174,7 +180,7 @@ class GaugeTrainer:
             flat, _, offsets = net.flat_params()
             segs.append((flat.data_ptr(), off, flat.numel(), offsets["b1"]))
             off += flat.numel()
-        trainable_eps = bool(dyn.eps_trainable)
+        trainable_eps = bool(dyn.eps_trainable) or not self.eager_variables
         gnorm = None
         if self.clip_value is not None:
             for i, (_, o, n, tri) in enumerate(segs):
@@ -225,7 +231,7 @@ class GaugeTrainer:
             lr = self.learning_rate()
             obs = u1_observables(x, T, X)
             loss, x_out, px, x_dq = self.train_step(x, beta)
-            _lib.check(_lib.lib().l2hmc_wrap_angle(x_out.data_ptr(), x_out.numel(), x.data_ptr(), _lib.stream_ptr()))
+            _lib.check(_lib.lib().l2hmc_wrap_angle(x_out.data_ptr(), x_out.numel(), x.data_ptr(), _lib.stream_ptr(self.dynamics._device)))
             for k, v in (("loss", loss), ("accept_prob", px.mean()), ("actions", obs["action"].mean()),
                          ("plaqs", obs["avg_plaq"].mean()), ("charges", obs["top_charge"]),
                          ("charge_diff", x_dq.sum() / float(x_dq.numel()))):

@@ -31,7 +31,7 @@ def u1_observables(x, time_size, space_size, beta=1.0, want_force=False):
     _lib.check(_lib.lib().l2hmc_u1_action_force(
         _lib.dev_ptr(x, name="x"), rows, time_size, space_size, float(beta), out["action"].data_ptr(),
         None if force is None else force.data_ptr(), out["avg_plaq"].data_ptr(),
-        out["top_charge"].data_ptr(), _lib.stream_ptr()))
+        out["top_charge"].data_ptr(), _lib.stream_ptr(x.device)))
     if want_force:
         out["force"] = force
     return out
@@ -91,7 +91,7 @@ class GaugeLattice(object):
         x = _x2d(samples, self.num_links)
         out = torch.empty(x.shape[0], self.time_size, self.space_size, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().l2hmc_u1_plaq_sums(_lib.dev_ptr(x, name="x"), x.shape[0], self.time_size,
-                                                 self.space_size, out.data_ptr(), _lib.stream_ptr()))
+                                                 self.space_size, out.data_ptr(), _lib.stream_ptr(x.device)))
         return out
 
     def grad_action(self, samples, beta=1.0):

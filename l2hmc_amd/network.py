@@ -50,6 +50,7 @@ class _DenseSTQ:
 
     @property
     def variables(self):
+        self.sync_reference_layout()     # a trainer may have moved the flat master copy since the last read
         out = []
         for layer in self._layers():
             out.extend(layer.variables)
@@ -59,6 +60,10 @@ class _DenseSTQ:
     trainable_variables = variables
 
     def state_dict(self):
+        """Reference-layout tensors by name.  Once a trainer owns the flat master copy (flat_params), the
+        optimiser only moves that buffer: every reader of the reference layout (this, `variables`,
+        `save_weights` -- the call gauge_model.py:549-554 makes after training) refreshes it first."""
+        self.sync_reference_layout()
         d = {}
         for n in self._layer_names:
             d[n + "/W"] = getattr(self, n).kernel
@@ -141,7 +146,7 @@ class _DenseSTQ:
         """After the flat buffer changed: rebuild the fragment-ordered image of the fused kernel."""
         if self._packed is not None and "packed" in self._packed[1]:
             st, bufs = self._packed
-            _lib.check(_lib.lib().l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr()))
+            _lib.check(_lib.lib().l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr(self._device)))
 
     def sync_reference_layout(self):
         """Flat training buffer -> reference-layout layer tensors (state_dict / save_weights read those).
@@ -177,7 +182,7 @@ class _DenseSTQ:
             nbytes = L.l2hmc_dense_pack_bytes(C.byref(st))
             if nbytes:      # fragment-ordered image for the fused whole-trajectory kernel
                 bufs["packed"] = torch.empty(nbytes // 4, dtype=torch.float32, device=self._device)
-                _lib.check(L.l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr()))
+                _lib.check(L.l2hmc_dense_pack(C.byref(st), bufs["packed"].data_ptr(), _lib.stream_ptr(self._device)))
                 st.packed = bufs["packed"].data_ptr()
             self._packed = (st, bufs)
         return self._packed[0]
@@ -196,7 +201,7 @@ class _DenseSTQ:
         ws, nb = self._ws.get(L.l2hmc_stq_ws_bytes(rows, st.H), a.device)
         _lib.check(L.l2hmc_stq_dense(C.byref(st), _lib.dev_ptr(a, name="a"), _lib.dev_ptr(b, name="b"), None,
                                      tc, ts, rows, S.data_ptr(), T.data_ptr(), Q.data_ptr(), ws, nb,
-                                     _lib.stream_ptr()))
+                                     _lib.stream_ptr(self._device)))
         return S, T, Q
 
     call = __call__
@@ -295,6 +300,7 @@ class ConvNet3D(_DenseSTQ):
 
     @property
     def variables(self):
+        self.sync_reference_layout()
         out = [self.coeff_scale, self.coeff_transformation]
         for n in self._conv_names:
             out.extend(getattr(self, n).variables)
@@ -360,7 +366,7 @@ class ConvNet3D(_DenseSTQ):
         ws, nb = self._ws.get(L.l2hmc_stq_conv3d_ws_bytes(rows, st.H, T, X, fr.F), a.device)
         _lib.check(L.l2hmc_stq_conv3d(C.byref(fr), C.byref(st), T, X, _lib.dev_ptr(a, name="a"),
                                       _lib.dev_ptr(b, name="b"), None, float(t[0, 0]), float(t[0, 1]), rows,
-                                      S.data_ptr(), Tr.data_ptr(), Q.data_ptr(), ws, nb, _lib.stream_ptr()))
+                                      S.data_ptr(), Tr.data_ptr(), Q.data_ptr(), ws, nb, _lib.stream_ptr(self._device)))
         return S, Tr, Q
 
     call = __call__

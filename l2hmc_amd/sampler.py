@@ -9,7 +9,7 @@ from . import _lib
 def _uniform(dynamics, n):
     out = torch.empty(n, dtype=torch.float32, device=dynamics._device)
     _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), n, dynamics._seed, dynamics._draws,
-                                             _lib.stream_ptr()))
+                                             _lib.stream_ptr(out.device)))
     dynamics._draws += 1
     return out
 
@@ -24,7 +24,7 @@ def tf_accept(x, Lx, px, u=None, dynamics=None):
     _lib.check(_lib.lib().l2hmc_mix_accept(
         x.data_ptr(), Lx.data_ptr(), Lx.data_ptr(), px.data_ptr(), Lx.data_ptr(), Lx.data_ptr(), px.data_ptr(),
         ones.data_ptr(), u.data_ptr(), 0, x.shape[0], x.shape[1], None, None, None, out.data_ptr(),
-        _lib.stream_ptr()))
+        _lib.stream_ptr(x.device)))
     return out
 
 
@@ -52,7 +52,7 @@ def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False,
         x.data_ptr(), Lx1.data_ptr(), Lv1.data_ptr(), px1.data_ptr(), Lx2.data_ptr(), Lv2.data_ptr(),
         px2.data_ptr(), mask.data_ptr(), None if u is None else _lib.as_dev(u, dynamics._device).data_ptr(),
         0, B, x.shape[1], Lx.data_ptr(), Lvm.data_ptr(), px.data_ptr(), None if out is None else out.data_ptr(),
-        _lib.stream_ptr()))
+        _lib.stream_ptr(x.device)))
     Lv = Lvm if init_v is not None else None       # :43-45 (quirk Q6)
     outputs = [out] if do_mh_step else []
     return Lx, Lv, px, outputs

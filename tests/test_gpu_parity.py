@@ -869,3 +869,39 @@ def test_fused_kernel_on_non_square_lattices(la, T, X):
     xn, px, obs, dq = smp.step(xs, beta)
     assert H.relerr(np_(obs["action"]), olat.total_action(x.astype(np.float32).astype(np.float64), T, X)) < TOL_OP
     assert H.relerr(np_(obs["top_charge"]), olat.top_charge(x.astype(np.float32).astype(np.float64), T, X)) < 1e-4
+
+
+def test_sampler_and_dynamics_share_one_draw_counter(la):
+    """GaugeSampler.step takes its Philox stream pair from dyn._draws (the counter _normal/_uniform
+    advance and save_state stores).  After dynamics draws the sampler's momenta are not a replay of them, and two
+    samplers on one dynamics never repeat each other's noise."""
+    from l2hmc_amd import _lib
+    T = X = 8
+    B = 32
+    orc, _, dyn = _pair(T, X, 2, 0.1, B, "mild")
+    x = torch.rand(B, 128, device="cuda") * (2 * np.pi)
+    v_first = dyn._normal((2 * B, 128)).clone()           # stream (seed, 0): what a fresh step_count=0 sampler used to replay
+    assert dyn._draws == 1
+    s1, s2 = la.GaugeSampler(dyn), la.GaugeSampler(dyn)
+    a = s1.step(x, 2.0)
+    assert dyn._draws == 4                                 # pair (2, 3)
+    b = s2.step(x, 2.0)
+    assert dyn._draws == 6                                 # pair (4, 5), not (2, 3) again
+    assert not torch.equal(a[1], b[1])                     # same x, different noise -> different accept probabilities
+    # the pair the first step consumed is stream 2 / 3, not the stream the dynamics already used
+    V = torch.empty(2 * B, 128, device="cuda")
+    _lib.check(_lib.lib().l2hmc_fill_normal(V.data_ptr(), V.numel(), dyn._seed, 2, None))
+    assert not torch.equal(V, v_first)
+    want = orc.apply_transition(np_(x), 2.0, np_(V[:B]), np_(V[B:]), *np.split(np_(_fill_u(dyn._seed, 3, 2 * B)), 2))
+    assert np.abs(np_(a[1]) - want[2]).max() < TOL_P
+    dyn.apply_transition(x, 2.0)                           # 4 single-stream draws
+    assert dyn._draws == 10
+    s1.step(x, 2.0)
+    assert dyn._draws == 12
+
+
+def _fill_u(seed, offset, n):
+    from l2hmc_amd import _lib
+    out = torch.empty(n, device="cuda")
+    _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), n, seed, offset, None))
+    return out

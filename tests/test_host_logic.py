@@ -289,3 +289,23 @@ def test_cpu_baseline_uses_a_sane_thread_count():
     r = time_cpu_baseline(4, 4, 2, 0.2, 2.0, 16, xp, vp, masks, budget_s=0.3)
     assert torch.get_num_threads() == before
     assert r["value"] > 0 and 1 <= r["cores"] <= r["cpus_available"] == n and r["calls"] >= 2
+
+
+def test_step_draw_counter_is_shared_and_never_reused():
+    """the native MCMC step takes its Philox stream pair from the dynamics' own draw counter, so a
+    sampler started after N dynamics draws (training, apply_transition) shares no stream with them, and two
+    samplers on one dynamics interleave instead of repeating each other."""
+    from l2hmc_amd._lib import step_draw_index
+    used = set()
+    draws = 0
+    for n_single in (0, 1, 9, 2250, 4):            # single-stream draws (_normal / _uniform) between steps
+        for _ in range(n_single):
+            assert draws not in used
+            used.add(draws)
+            draws += 1
+        for _ in range(3):                          # three native steps
+            d, draws = step_draw_index(draws)
+            pair = {2 * d, 2 * d + 1}
+            assert not (pair & used) and draws == 2 * d + 2
+            used |= pair
+    assert step_draw_index(0) == (0, 2) and step_draw_index(1) == (1, 4) and step_draw_index(2) == (1, 4)
