@@ -60,6 +60,18 @@ def build_dynamics(batch, both_directions=True, arch='generic'):
     return dyn, xp, vp, dyn.mask.cpu().numpy()
 
 
+def committed_traffic():
+    """(bytes per launch, file) from the newest profiles/r*_pmc_fused_kernel.json, or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fused_kernel.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return int(json.load(f)["hbm_side"]["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
+
+
 def launch_command(gpus, env, argv, port=None):
     """The decision the driver's bare `python bench.py --gpus N` needs (gauge_model.py:2041 relies on mpirun to
     start the ranks; here the script starts its own): None when this process IS a rank (WORLD_SIZE is set by
@@ -247,12 +259,16 @@ def main():
         stats.wait()
         per_class = {k: v for k, v in per_class.items() if v["launches"]}
         dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
-        # fabric-side bytes per launch of the fused kernel at this exact shape, from the committed PMC passes
-        # (profiles/r01_pmc_fused_kernel.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction); null otherwise
-        traffic = 315824250 if (dom["kernel"].startswith("gauge_traj_fused") and both) else None
+        # fabric-side bytes per launch of the fused kernel at this exact shape: read from the newest committed PMC
+        # summary (tools/pmc_collect.sh + tools/pmc_summary.py -> profiles/rNN_pmc_fused_kernel.json); null if the
+        # dominant kernel is another one or no summary is committed -- never a literal
+        traffic, traffic_src = None, None
+        if dom["kernel"].startswith("gauge_traj_fused") and both:
+            traffic, traffic_src = committed_traffic()
         out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "bytes per launch (rocprofv3 --pmc, see profiles/r01_pmc_fused_kernel.json)",
+                           "traffic_unit": "bytes per launch, fabric side: 2 x FETCH_SIZE + WRITE_SIZE from separate "
+                                           f"rocprofv3 --pmc passes ({traffic_src})",
                            "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
                            "algorithmic_flops_per_launch": dom["flops_per_launch"],
                            "all_kernels": list(per_class.values()),

@@ -9,13 +9,24 @@ abs deviation relative to the tensor's own scale (>= 1).
     ~100x over 10 steps (single steps agree to ~2e-7, the fp32 floor), so even
     the reference's own fp32 graph is ~1e-5 away from exact arithmetic at the
     end: the fp32 NumPy oracle (same op order as the reference) measures that
-    intrinsic deviation on the same inputs.  The HIP result must be
-    indistinguishable from such an fp32 evaluation: max error <= max(TOL_OP,
-    6 x intrinsic max) and RMS error <= max(TOL_OP / 3, 2.5 x intrinsic RMS)
-    against the fp64 oracle (the max over ~10^4 chaotically amplified elements
-    is heavy-tailed, hence two norms).  On benign dynamics (small step, near-cold
-    start) the whole trajectory is held to TOL_OP outright
-    (test_trajectory_within_1e5_on_benign_dynamics).
+    intrinsic deviation on the same inputs.  The allowance over it is MEASURED
+    (tools/error_ratio.py -> profiles/r02_error_ratio_*.txt; per leapfrog step,
+    x / v / log-det / p, fused and layered, cfg 3 / cfg 3 conv / cfg 4 dynamics):
+      - averaged over samples the HIP error is 0.7-1.1 x the fp32 oracle's for
+        x and v at every step (it is usually SMALLER: fp64 energy differences,
+        fused multiply-adds), <= 1.4 x for the log-det while that is < 1e-6;
+      - RMS over a sample's elements: <= 1.0 x where it binds at cfg 3, worst
+        single sample 1.47 x (cfg 4, 16 chains)       -> RMS_RATIO = 1.6;
+      - the MAX over a sample's ~10^4 chaotically amplified elements is an
+        extreme value of a heavy-tailed distribution on both sides: the ratio of
+        the two maxima scatters (worst of 96 32-chain trajectories 4.08, typical
+        0.7-1.3; the libm-exp/tanh diagnostic build scatters the same, 5.08) ->
+        MAX_RATIO = 4.5 is an extreme-value allowance, not a precision one;
+      - accept probability: a few chains per sample have p != 0, so the max
+        ratio scatters most (typical <= 2.2)          -> P_RATIO = 6.
+    Both apply only above the absolute bars (TOL_OP max, TOL_OP / 3 RMS, TOL_P):
+    on benign dynamics (small step, near-cold start) the whole trajectory is
+    held to TOL_OP outright (test_trajectory_within_1e5_on_benign_dynamics).
 """
 import os
 
@@ -30,6 +41,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_OP = 1e-5
 TOL_P = 2e-5
+MAX_RATIO, RMS_RATIO, P_RATIO = 4.5, 1.6, 6.0      # measured allowance over the fp32 oracle's own error (docstring)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -46,8 +58,8 @@ def assert_fp32_equivalent(got, want64, want32, what):
     """`got` is as close to the fp64 oracle as an fp32 evaluation in the reference's op order."""
     emax, imax = H.relerr(got, want64), H.relerr(want32, want64)
     erms, irms = rmserr(got, want64), rmserr(want32, want64)
-    assert emax < max(TOL_OP, 6 * imax), f"{what}: max err {emax:.2e} vs intrinsic fp32 {imax:.2e}"
-    assert erms < max(TOL_OP / 3, 2.5 * irms), f"{what}: rms err {erms:.2e} vs intrinsic fp32 {irms:.2e}"
+    assert emax < max(TOL_OP, MAX_RATIO * imax), f"{what}: max err {emax:.2e} vs intrinsic fp32 {imax:.2e}"
+    assert erms < max(TOL_OP / 3, RMS_RATIO * irms), f"{what}: rms err {erms:.2e} vs intrinsic fp32 {irms:.2e}"
 
 
 @pytest.fixture(scope="module")
@@ -188,7 +200,7 @@ def test_transition_kernel_both_directions(la, T, X, N, eps, beta, B, regime, fu
         assert_fp32_equivalent(np_(xo), want[0], f32[0], "x")
         assert_fp32_equivalent(np_(vo), want[1], f32[1], "v")
         assert_fp32_equivalent(np_(sld), want[3], f32[3], "sumlogdet")
-        assert np.abs(np_(p) - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+        assert np.abs(np_(p) - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())
 
 
 def test_trajectory_within_1e5_on_benign_dynamics(la):
@@ -221,7 +233,7 @@ def test_apply_transition_matches_oracle_in_both_modes(la, T, X, N, eps, beta, B
         outs[both] = [np_(g) for g in got]
         assert_fp32_equivalent(outs[both][0], want[0], f32[0], "x_prop")
         assert_fp32_equivalent(outs[both][1], want[1], f32[1], "v_prop")
-        assert np.abs(outs[both][2] - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+        assert np.abs(outs[both][2] - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())
         safe = np.abs(want[2] - u) > 1e-4        # accept decisions can only flip where p - u is within rounding
         assert_fp32_equivalent(outs[both][3][safe], want[3][safe], f32[3][safe], "x_out")
         acc = outs[both][2] > u
@@ -337,7 +349,7 @@ def test_conv3d_dynamics_matches_oracle(la, L, N, B, regime):
         got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
         assert_fp32_equivalent(got[0], want[0], f32[0], "x_prop")
         assert_fp32_equivalent(got[1], want[1], f32[1], "v_prop")
-        assert np.abs(got[2] - want[2]).max() < max(TOL_P, 6 * np.abs(f32[2] - want[2]).max())
+        assert np.abs(got[2] - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())
     dyn.fused = True
 
 
@@ -362,19 +374,25 @@ def test_golden_gauge(la, name, fused):
     S, Tt, Q = dyn.momentum_fn([g["x"], g["grad0"], dyn._format_time(0)])
     assert H.relerr(np_(S), g["stq0_S"]) < TOL_OP and H.relerr(np_(Tt), g["stq0_T"]) < TOL_OP
     assert H.relerr(np_(Q), g["stq0_Q"]) < TOL_OP
-    # step-by-step trace of the forward trajectory
+    # step-by-step trace of the forward trajectory against the committed fp64 trace; the fp32 oracle (same
+    # weights, run here) measures what the reference's own precision costs at every step
+    orc32 = H.gauge_oracle(T, X, N, float(g["eps"]), xp, vp, arch=arch, dtype=np.float32)
+    orc32.mask = g["masks"].astype(np.float32)
+    t32 = []
+    orc32.transition_kernel(g["x"].astype(np.float32), beta, g["v0f"].astype(np.float32), forward=True, trace=t32)
     x, v = g["x"], g["v0f"]
     ld = np.zeros(B)
-    tol = TOL_OP
     for step in range(N):
         x, v, dl = dyn._forward_lf(x, v, beta, step)
         ld = ld + np_(dl)
-        tol = tol * (1.0 if name == "gauge_L4_stress" else 1.2)   # error budget grows with the dynamics
-        assert H.relerr(np_(x), g["traj_f/x_steps"][step]) < tol, step
-        assert H.relerr(np_(v), g["traj_f/v_steps"][step]) < tol, step
-        assert H.relerr(ld, g["traj_f/logdet_steps"][step]) < tol, step
+        assert_fp32_equivalent(np_(x), g["traj_f/x_steps"][step], t32[step][0], f"x after step {step}")
+        assert_fp32_equivalent(np_(v), g["traj_f/v_steps"][step], t32[step][1], f"v after step {step}")
+        assert_fp32_equivalent(ld, g["traj_f/logdet_steps"][step], t32[step][2], f"log-det after step {step}")
     got = dyn.apply_transition(g["x"], beta, momentum_f=g["v0f"], momentum_b=g["v0b"], coin=g["coin"], u=g["u"])
-    assert H.relerr(np_(got[0]), g["x_prop"]) < 5 * TOL_OP and np.abs(np_(got[2]) - g["p_accept"]).max() < TOL_P
+    f32 = orc32.apply_transition(g["x"].astype(np.float32), beta, g["v0f"].astype(np.float32),
+                                 g["v0b"].astype(np.float32), g["coin"], g["u"].astype(np.float32))
+    assert_fp32_equivalent(np_(got[0]), g["x_prop"], f32[0], "x_prop")
+    assert np.abs(np_(got[2]) - g["p_accept"]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - g["p_accept"]).max())
 
 
 # ----------------------------------------------------------------- toy targets / generic Dynamics
@@ -730,6 +748,7 @@ def test_selected_only_step_equals_both_directions_step(la, arch, fused, B):
     res = {}
     for both in (True, False):
         dyn.both_directions = both
+        dyn._draws = 0                                  # replay the same Philox streams in both modes
         smp = la.GaugeSampler(dyn)
         x, hist = x0.clone(), []
         for _ in range(3):
@@ -905,3 +924,88 @@ def _fill_u(seed, offset, n):
     out = torch.empty(n, device="cuda")
     _lib.check(_lib.lib().l2hmc_fill_uniform(out.data_ptr(), n, seed, offset, None))
     return out
+
+
+# ----------------------------------------------------------------- BASELINE.json configs[4] and configs[3] widths
+@pytest.fixture(scope="module")
+def cfg5():
+    """U(1) 32x32, GenericNet D=2048 / H=8192 (gauge_dynamics.py:169-187: num_hidden = 4 x_dim), beta 4, eps 0.1,
+    25 LF steps.  151 M parameters per network: built once for the tests below."""
+    T = X = 32
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    xp32 = {k: v.astype(np.float32).astype(np.float64) for k, v in xp.items()}   # the values the device holds
+    vp32 = {k: v.astype(np.float32).astype(np.float64) for k, v in vp.items()}
+    del xp, vp
+    return T, X, xp32, vp32
+
+
+def test_cfg5_leapfrog_steps_at_full_width(la, cfg5):
+    """`_forward_lf` / `_backward_lf` (gauge_dynamics.py:412-483) at step 0 and N-1 of the 25-step schedule."""
+    T, X, xp, vp = cfg5
+    N, eps, beta, B, D = 25, 0.1, 4.0, 6, 2 * T * X
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    assert dyn.position_fn.num_hidden == 8192 and dyn.x_dim == 2048
+    x, v, _, _, _ = H.gauge_inputs(B, D, seed=105)
+    x, v = x.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    for step in (0, N - 1):
+        for fn, ofn in ((dyn._forward_lf, orc._forward_lf), (dyn._backward_lf, orc._backward_lf)):
+            x1, v1, ld = fn(x, v, beta, step)
+            ox, ov, old = ofn(x, v, beta, step)
+            assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP, (step, fn.__name__)
+            assert H.relerr(np_(ld), old) < TOL_OP, (step, fn.__name__)
+            assert np.abs(old).max() > 1e-3                      # the log-det path is exercised
+    # inverse pair at full width (:537-590)
+    x1, v1, ld = dyn._forward_lf(x, v, beta, 3)
+    x2, v2, ld2 = dyn._backward_lf(x1, v1, beta, N - 1 - 3)
+    assert H.relerr(np_(x2), x) < 2e-5 and H.relerr(np_(v2), v) < 2e-5 and H.relerr(np_(ld2), -np_(ld)) < 2e-5
+
+
+def test_cfg5_transition_kernel_and_apply_transition_at_full_width(la, cfg5):
+    """A 3-step `transition_kernel` in both directions and one `apply_transition` (:195-313, :592-609)
+    at D=2048 / H=8192 against the fp64 oracle at the single-op bar."""
+    T, X, xp, vp = cfg5
+    N, eps, beta, B, D = 3, 0.1, 4.0, 5, 2 * T * X
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, D, seed=105)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)     # noqa: E731
+    x, v0f, v0b, u = f32(x), f32(v0f), f32(v0b), f32(u)
+    for fwd, v0 in ((True, v0f), (False, v0b)):
+        xo, vo, p, sld = dyn.transition_kernel(x, beta, forward=fwd, momentum=v0, return_logdet=True)
+        want = orc.transition_kernel(x, beta, v0, forward=fwd)
+        assert H.relerr(np_(xo), want[0]) < TOL_OP and H.relerr(np_(vo), want[1]) < TOL_OP, fwd
+        assert H.relerr(np_(sld), want[3]) < TOL_OP and np.abs(np_(p) - want[2]).max() < TOL_P, fwd
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    for both in (True, False):
+        dyn.both_directions = both
+        got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
+        assert H.relerr(got[0], want[0]) < TOL_OP and H.relerr(got[1], want[1]) < TOL_OP
+        assert np.abs(got[2] - want[2]).max() < TOL_P
+        safe = np.abs(want[2] - u) > 1e-4
+        assert H.relerr(got[3][safe], want[3][safe]) < TOL_OP
+
+
+def test_cfg4_conv3d_at_its_real_trajectory_length(la):
+    """BASELINE.json configs[3]: 16x16, ConvNet3D F=16 / H=1024, the real N_LF = 15 (eps 0.2, beta 3, hot start),
+    a handful of chains: single steps at the first and last index at the 1e-5 bar, the whole 15-step transition
+    within the measured fp32 envelope (profiles/r02_error_ratio_*.txt)."""
+    L, N, eps, beta, B = 16, 15, 0.2, 3.0, 5
+    D = 2 * L * L
+    xp, vp = H.conv_weights(L, L, regime="init")
+    orc = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D')
+    orc32 = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D', dtype=np.float32)
+    dyn = H.gauge_hip(L, L, N, eps, xp, vp, orc.mask, B, arch='conv3D')
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, D, seed=104)
+    for step in (0, N - 1):
+        for fn, ofn in ((dyn._forward_lf, orc._forward_lf), (dyn._backward_lf, orc._backward_lf)):
+            x1, v1, ld = fn(x, v0f, beta, step)
+            ox, ov, old = ofn(x, v0f, beta, step)
+            assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP and H.relerr(np_(ld), old) < TOL_OP
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    f32 = orc32.apply_transition(x.astype(np.float32), beta, v0f.astype(np.float32), v0b.astype(np.float32), coin,
+                                 u.astype(np.float32))
+    got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
+    assert_fp32_equivalent(got[0], want[0], f32[0], "x_prop")
+    assert_fp32_equivalent(got[1], want[1], f32[1], "v_prop")
+    assert np.abs(got[2] - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())

@@ -1,0 +1,142 @@
+"""How far is the HIP trajectory from exact arithmetic, in units of what fp32 itself costs?
+
+For every leapfrog step of a trajectory at given dynamics this measures, against the float64 oracle,
+    e_hip  = error of the HIP path (fused whole-trajectory kernel / layer-by-layer kernels)
+    e_f32  = error of the float32 NumPy oracle (the reference's precision and op order)
+for x, v, the accumulated log-det (max norm and RMS, both relative to max(1, max|exact|)) and, at the end of the
+trajectory, the accept probability -- and prints the ratio e_hip / e_f32.  The parity tests' allowance for
+chaotic trajectories (tests/test_gpu_parity.py: assert_fp32_equivalent) is set from this table.
+
+    python tools/error_ratio.py [cfg3|cfg3conv|cfg4] [--lib path/to/alternative/libl2hmc_hip.so]
+
+The --lib switch loads a diagnostic build (tools/build_exact.sh: libm expf/tanhf instead of the v_exp_f32 /
+v_rcp_f32 forms) to show how much of the error the hardware transcendental forms account for.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config", nargs="?", default="cfg3", choices=["cfg3", "cfg3conv", "cfg4"])
+ap.add_argument("--lib", default=None)
+ap.add_argument("--chains", type=int, default=128)
+ap.add_argument("--seeds", type=int, default=4)
+ap.add_argument("--regimes", default="init,mild")
+args = ap.parse_args()
+
+from l2hmc_amd import _lib  # noqa: E402
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+import torch  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+CFG = {  # L, N, eps, beta, arch   (SURVEY.md 8d synthetic inputs)
+    "cfg3": (8, 10, 0.25, 2.0, "generic"),
+    "cfg3conv": (8, 10, 0.25, 2.0, "conv3D"),
+    "cfg4": (16, 15, 0.2, 3.0, "conv3D"),
+}
+
+
+def rel(got, want):
+    return float(np.max(np.abs(got - want)) / max(1.0, np.max(np.abs(want))))
+
+
+def rms(got, want):
+    return float(np.sqrt(np.mean((got - want) ** 2)) / max(1.0, np.max(np.abs(want))))
+
+
+def np_(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def main():
+    L, N, eps, beta, arch = CFG[args.config]
+    D, B = 2 * L * L, args.chains
+    print(f"# {args.config}: U(1) {L}x{L}, {arch}, N_LF={N}, eps={eps}, beta={beta}, hot start, {B} chains x "
+          f"{args.seeds} seeds, both directions; library: {_lib.LIB_PATH}")
+    print("# e = error vs the float64 oracle relative to max(1, max|exact|); ratio = e_hip / e_f32 "
+          "(f32 = NumPy float32 oracle, the reference's precision and op order)")
+    worst = {}
+    for regime in args.regimes.split(","):
+        mk = H.conv_weights if arch == "conv3D" else H.gauge_weights
+        xp, vp = mk(L, L, regime=regime)
+        o64 = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch)
+        o32 = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch, dtype=np.float32)
+        dyn = H.gauge_hip(L, L, N, eps, xp, vp, o64.mask, B, arch=arch)
+        for fused in (True, False):
+            dyn.fused = fused
+            path = "fused" if fused else "layered"
+            # accumulate over seeds and directions: per step, per quantity -> lists of (e_hip, e_f32)
+            acc = {(s, q, n): [] for s in range(N) for q in "xvl" for n in ("max", "rms")}
+            pacc, whole = [], []
+            for seed in range(args.seeds):
+                x0, v0f, v0b, _, _ = H.gauge_inputs(B, D, seed=103 + 17 * seed)
+                for fwd, v0 in ((True, v0f), (False, v0b)):
+                    t64, t32 = [], []
+                    w64 = o64.transition_kernel(x0, beta, v0, forward=fwd, trace=t64)
+                    w32 = o32.transition_kernel(x0.astype(np.float32), beta, v0.astype(np.float32), forward=fwd,
+                                                trace=t32)
+                    x, v = x0, v0
+                    ld = np.zeros(B)
+                    lf = dyn._forward_lf if fwd else dyn._backward_lf
+                    for s in range(N):
+                        x, v, dl = lf(x, v, beta, s)
+                        ld = ld + np_(dl)
+                        for q, g, a, b in (("x", np_(x), t64[s][0], t32[s][0]), ("v", np_(v), t64[s][1], t32[s][1]),
+                                           ("l", ld, t64[s][2], t32[s][2])):
+                            acc[(s, q, "max")].append((rel(g, a), rel(b.astype(np.float64), a)))
+                            acc[(s, q, "rms")].append((rms(g, a), rms(b.astype(np.float64), a)))
+                    # the whole-trajectory launch (what sampling runs) must reproduce the stepwise result
+                    xo, vo, p, sld = dyn.transition_kernel(x0, beta, forward=fwd, momentum=v0, return_logdet=True)
+                    whole.append(max(rel(np_(xo), np_(x)), rel(np_(vo), np_(v))))
+                    dp_h, dp_f = np_(p) - w64[2], w32[2].astype(np.float64) - w64[2]
+                    pacc.append((float(np.max(np.abs(dp_h))), float(np.max(np.abs(dp_f))),
+                                 float(np.sqrt(np.mean(dp_h ** 2))), float(np.sqrt(np.mean(dp_f ** 2)))))
+            print(f"\n## regime {regime}, {path} path   (whole-trajectory launch vs stepwise launches: max rel diff "
+                  f"{max(whole):.1e})")
+            print("step |      x: e_hip   e_f32  ratio |      v: e_hip   e_f32  ratio | logdet: e_hip   e_f32  ratio"
+                  " |  rms ratios x / v / logdet")
+            for s in range(N):
+                row = [f"{s + 1:4d} |"]
+                rr = []
+                for q in "xvl":
+                    eh = np.mean([a for a, _ in acc[(s, q, "max")]])
+                    ef = np.mean([b for _, b in acc[(s, q, "max")]])
+                    row.append(f"       {eh:8.2e} {ef:8.2e} {eh / max(ef, 1e-300):6.2f} |")
+                    rh = np.mean([a for a, _ in acc[(s, q, "rms")]])
+                    rf = np.mean([b for _, b in acc[(s, q, "rms")]])
+                    rr.append(rh / max(rf, 1e-300))
+                    # the assertion in the tests compares single samples: keep the worst single-sample ratio too
+                    single = max(a / max(b, 1e-300) for a, b in acc[(s, q, "max")] if a > 1e-5) \
+                        if any(a > 1e-5 for a, _ in acc[(s, q, "max")]) else 0.0
+                    singler = max(a / max(b, 1e-300) for a, b in acc[(s, q, "rms")] if a > 1e-5 / 3) \
+                        if any(a > 1e-5 / 3 for a, _ in acc[(s, q, "rms")]) else 0.0
+                    worst[(regime, path, "max")] = max(worst.get((regime, path, "max"), 0.0), single)
+                    worst[(regime, path, "rms")] = max(worst.get((regime, path, "rms"), 0.0), singler)
+                row.append("  " + " / ".join(f"{r:5.2f}" for r in rr))
+                print(" ".join(row))
+            ph = np.mean([a for a, _, _, _ in pacc])
+            pf = np.mean([b for _, b, _, _ in pacc])
+            # single-sample ratios only where the HIP error exceeds the absolute bar the tests apply first (2e-5)
+            psingle = max([a / max(b, 1e-300) for a, b, _, _ in pacc if a > 2e-5] or [0.0])
+            prms = max([c / max(d, 1e-300) for _, _, c, d in pacc if c > 2e-5 / 3] or [0.0])
+            print(f"accept probability (abs): max-norm e_hip {ph:.2e}  e_f32 {pf:.2e}  ratio of means {ph / max(pf, 1e-300):.2f}  "
+                  f"worst e_hip {max(a for a, _, _, _ in pacc):.2e};  rms e_hip {np.mean([c for _, _, c, _ in pacc]):.2e}  "
+                  f"e_f32 {np.mean([d for _, _, _, d in pacc]):.2e}")
+            worst[(regime, path, "p max")] = psingle
+            worst[(regime, path, "p rms")] = prms
+    print("\n# worst SINGLE-SAMPLE ratio e_hip / e_f32 (one sample = one direction of one seed's chains) over all steps, "
+          "counted only where e_hip exceeds the absolute bar the tests apply first (1e-5 max / 3.3e-6 rms; 2e-5 / 6.7e-6 "
+          "for p): 0.00 = never above the bar.  This is what assert_fp32_equivalent has to allow:")
+    for k in sorted(worst):
+        print(f"#   {k[0]:>6} {k[1]:>8} {k[2]:>6}: {worst[k]:.2f}")
+
+
+if __name__ == "__main__":
+    assert torch.cuda.is_available(), "needs a GPU"
+    main()
