@@ -35,12 +35,18 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // ---------------------------------------------------------------------------
 // streaming GEMM core: acc[t] += A(16 x 16*NKC) . Wpacked, one wave, NT tiles
 // ---------------------------------------------------------------------------
+// The WEIGHT fragment is the MFMA's first operand and the activation fragment its second: the product is formed
+// transposed, C^T[col][row], so lane (q = lane / 16, r = lane % 16) ends up with out[row r][tile * 16 + 4 q + e],
+// e = 0..3 -- four CONSECUTIVE COLUMNS of ONE row.  Every epilogue access (bias, masks, x / v / force, the h1 / h2
+// rows the next layer reads as its k-contiguous fragments) is then one 16-byte LDS instruction instead of four
+// 4-byte ones, and a row's log-det needs two cross-lane steps instead of four.  The packed weight image and the
+// activation fragment reads are the same for either operand order (A[i][k] and B[k][j] use the same lane map).
 template <int NT>
 __device__ __forceinline__ void mfma_block(const f32x4 a, const f32x4 (&b)[NT], f32x4 (&acc)[NT]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[t][e], acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][e], a[e], acc[t], 0, 0, 0);
 }
 
 template <int NT>

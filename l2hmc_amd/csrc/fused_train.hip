@@ -295,12 +295,12 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
             R1, wpb1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
         ring_prime<NT1>(R2, wpb2);
 #pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-          const int col = (wave * NT1 + t) * 16 + r;
+        for (int t = 0; t < NT1; ++t) {       // lane (q, r): row r, columns c0 .. c0 + 3 (fused_common.h)
+          const int c0 = (wave * NT1 + t) * 16 + q * 4;
+          f32x4 g;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            d2s[(q * 4 + e) * SH + col] = ((gate2 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
-          }
+          for (int e = 0; e < 4; ++e) g[e] = ((gate2 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
+          *reinterpret_cast<f32x4*>(d2s + r * SH + c0) = g;
         }
       }
       __syncthreads();
@@ -318,11 +318,11 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
         ring_prime<NT3>(R3, wpb3);
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
-          const int col = (wave * NT1 + t) * 16 + r;
+          const int c0 = (wave * NT1 + t) * 16 + q * 4;
+          f32x4 g;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            d1s[(q * 4 + e) * SH + col] = ((gate1 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
-          }
+          for (int e = 0; e < 4; ++e) g[e] = ((gate1 >> (t * 4 + e)) & 1u) ? acc[t][e] : 0.f;
+          *reinterpret_cast<f32x4*>(d1s + r * SH + c0) = g;
         }
       }
       __syncthreads();
@@ -339,11 +339,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
         stream_layer<NT3, Cfg::KCH>(
             R3, wpb3, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
 #pragma unroll
-        for (int t = 0; t < NT3; ++t) {
-          const int col = (wave * NT3 + t) * 16 + r;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dis[(q * 4 + e) * SI + col] = acc[t][e];
-        }
+        for (int t = 0; t < NT3; ++t)
+          *reinterpret_cast<f32x4*>(dis + r * SI + (wave * NT3 + t) * 16 + q * 4) = acc[t];
       }
       __syncthreads();
 

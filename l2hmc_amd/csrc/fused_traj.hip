@@ -231,9 +231,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   if (tid < kFWaves * kFM) ldw[tid] = 0.f;
   __syncthreads();
 
-  int dirr[4];                        // direction of the 4 rows this lane owns in a C fragment
-#pragma unroll
-  for (int e = 0; e < 4; ++e) dirr[e] = sdir[q * 4 + e];
+  const int dirl = sdir[r];           // direction of the row this lane owns in a C fragment (fused_common.h)
 
   // ---- chain-local passes: kTPC consecutive threads per chain ------------------
   const int fc = tid / kTPC, fl = tid % kTPC;      // chain, lane-in-chain
@@ -377,8 +375,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   // l1: 0 = compute both halves; 1 = as 0 and store the raw product in keep_v; 2 = take keep_v, no GEMM;
   //     3 = compute, snapshot the first-input half into keep_x; 4 = start from keep_x, second half only.
   auto net_update = [&](const l2hmc_dense_net& net, const float* cn, const float* in1, int mode, int sub,
-                        bool prep_next_mask, int l1, bool is_vnet, const float (&tcr)[4],
-                        const float (&tsr)[4], int callidx) {
+                        bool prep_next_mask, int l1, bool is_vnet, const float tcr, const float tsr,
+                        int callidx) {
     const float* pk = net.packed;
     // training tape (generic plans): this call's inputs and the state its sub-update consumes
     [[maybe_unused]] const FusedTape& tp = is_vnet ? p.tv : p.tx;
@@ -472,14 +470,17 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       [[maybe_unused]] unsigned gmask = 0;
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
-        const int col = (wave * NT1 + t) * 16 + r;
-        const float b = cn[col], w0 = cn[H + col], w1 = cn[2 * H + col];
+        const int c0 = (wave * NT1 + t) * 16 + q * 4;          // this lane: row r, columns c0 .. c0 + 3
+        const f32x4 b = *reinterpret_cast<const f32x4*>(cn + c0);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(cn + H + c0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(cn + 2 * H + c0);
+        f32x4 hv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float hv = fmaxf(acc[t][e] + b + (tcr[e] * w0 + tsr[e] * w1), 0.f);
-          h1[(q * 4 + e) * SH + col] = hv;
-          if constexpr (TAPE) gmask |= (hv > 0.f ? 1u : 0u) << (t * 4 + e);
+          hv[e] = fmaxf(acc[t][e] + b[e] + (tcr * w0[e] + tsr * w1[e]), 0.f);
+          if constexpr (TAPE) gmask |= (hv[e] > 0.f ? 1u : 0u) << (t * 4 + e);
         }
+        *reinterpret_cast<f32x4*>(h1 + r * SH + c0) = hv;
       }
       if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 0) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
       FT_ADD(3, t0);
@@ -505,14 +506,15 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       [[maybe_unused]] unsigned gmask = 0;
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
-        const int col = (wave * NT1 + t) * 16 + r;
-        const float b = cn[3 * H + col];
+        const int c0 = (wave * NT1 + t) * 16 + q * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(cn + 3 * H + c0);
+        f32x4 hv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float hv = fmaxf(acc[t][e] + b, 0.f);
-          h2[(q * 4 + e) * SH + col] = hv;
-          if constexpr (TAPE) gmask |= (hv > 0.f ? 1u : 0u) << (t * 4 + e);
+          hv[e] = fmaxf(acc[t][e] + b[e], 0.f);
+          if constexpr (TAPE) gmask |= (hv[e] > 0.f ? 1u : 0u) << (t * 4 + e);
         }
+        *reinterpret_cast<f32x4*>(h2 + r * SH + c0) = hv;
       }
       if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 1) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
       FT_ADD(4, t0);
@@ -534,72 +536,86 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
           R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
       FT_ADD(2, t0);
       t0 = FT_NOW();
-      float ld[4] = {0.f, 0.f, 0.f, 0.f};
+      float ld = 0.f;                       // this lane's share of row r's log-det
       const float* bhd = cn + 4 * H;
       const float* es = bhd + 3 * D;
       const float* eq = es + D;
+      const int d = dirl;
 #pragma unroll
       for (int t = 0; t < NTH; ++t) {
-        const int col = wave * (D / kFWaves) + t * 16 + r;
-        const float b_s = bhd[col], b_t = bhd[D + col], b_q = bhd[2 * D + col];
-        const float e_s = es[col], e_q = eq[col];
-        const float mf = skm[col], mb = skm[D + col];
+        const int c0 = wave * (D / kFWaves) + t * 16 + q * 4;      // row r, columns c0 .. c0 + 3
+        const f32x4 b_s = *reinterpret_cast<const f32x4*>(bhd + c0);
+        const f32x4 b_t = *reinterpret_cast<const f32x4*>(bhd + D + c0);
+        const f32x4 b_q = *reinterpret_cast<const f32x4*>(bhd + 2 * D + c0);
+        const f32x4 e_s = *reinterpret_cast<const f32x4*>(es + c0);
+        const f32x4 e_q = *reinterpret_cast<const f32x4*>(eq + c0);
+        const f32x4 mf = *reinterpret_cast<const f32x4*>(skm + c0);
+        const f32x4 mb = *reinterpret_cast<const f32x4*>(skm + D + c0);
+        const int idx = r * SX + c0;
+        f32x4 S, Tt, Q;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = q * 4 + e;
-          const int d = dirr[e];
-          const float S = fast_tanh(acc[0 * NTH + t][e] + b_s) * e_s;
-          const float Tt = acc[1 * NTH + t][e] + b_t;
-          float Q = acc[2 * NTH + t][e] + b_q;
-          Q = (net.q_tanh ? fast_tanh(Q) : Q) * e_q;
-          const int idx = row * SX + col;
-          if constexpr (TAPE) {
-            if (row < nrow) {
-              const size_t plane = (size_t)p.rows * D;
-              float* o = tp.stq + (size_t)callidx * 3 * plane + ((size_t)row0 + row) * D + col;
-              o[0] = S;
-              o[plane] = Tt;
-              o[2 * plane] = Q;
-            }
-          }
-          if (mode == 1) {
-            // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
-            const float g = gs[idx], v = vs[idx];
-            const float s = (d ? -0.5f : 0.5f) * eps * S;
-            const float kick = 0.5f * eps * (fast_exp(eps * Q) * g - Tt);
-            const float es_ = fast_exp(s);
-            vs[idx] = d ? es_ * (v + kick) : v * es_ - kick;
-            ld[e] += s;
-            // the next net call is the first position sub-update: its second input is keep (.) x
-            if (prep_next_mask) {
-              const float k0 = d ? 1.f - mb : mf;
-              gs[idx] = k0 * xs[idx];
-            }
-          } else {
-            // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd); keep mask per direction and sub-update
-            const float keep = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf);
-            const float x = xs[idx], v = vs[idx];
-            const float s = (d ? -eps : eps) * S;
-            const float drift = eps * (fast_exp(eps * Q) * v + Tt);
-            const float es_ = fast_exp(s);
-            const float upd = d ? es_ * (x - drift) : x * es_ + drift;
-            const float xn = keep * x + (1.f - keep) * upd;
-            xs[idx] = xn;
-            ld[e] += (1.f - keep) * s;
-            // second sub-update follows: its keep mask is the complement (gauge_dynamics.py:434-437, :472-475)
-            if (prep_next_mask) gs[idx] = (1.f - keep) * xn;
+          S[e] = fast_tanh(acc[0 * NTH + t][e] + b_s[e]) * e_s[e];
+          Tt[e] = acc[1 * NTH + t][e] + b_t[e];
+          const float qq = acc[2 * NTH + t][e] + b_q[e];
+          Q[e] = (net.q_tanh ? fast_tanh(qq) : qq) * e_q[e];
+        }
+        if constexpr (TAPE) {
+          if (r < nrow) {
+            const size_t plane = (size_t)p.rows * D;
+            float* o = tp.stq + (size_t)callidx * 3 * plane + ((size_t)row0 + r) * D + c0;
+            *reinterpret_cast<f32x4*>(o) = S;
+            *reinterpret_cast<f32x4*>(o + plane) = Tt;
+            *reinterpret_cast<f32x4*>(o + 2 * plane) = Q;
           }
         }
-      }
+        if (mode == 1) {
+          // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
+          const f32x4 g = *reinterpret_cast<const f32x4*>(gs + idx);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(vs + idx);
+          f32x4 vn;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = ld[e];
-        t += __shfl_xor(t, 8, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 1, 64);
-        if (r == 0) ldw[wave * kFM + q * 4 + e] += t;
+          for (int e = 0; e < 4; ++e) {
+            const float s = (d ? -0.5f : 0.5f) * eps * S[e];
+            const float kick = 0.5f * eps * (fast_exp(eps * Q[e]) * g[e] - Tt[e]);
+            const float es_ = fast_exp(s);
+            vn[e] = d ? es_ * (v[e] + kick) : v[e] * es_ - kick;
+            ld += s;
+          }
+          *reinterpret_cast<f32x4*>(vs + idx) = vn;
+          // the next net call is the first position sub-update: its second input is keep (.) x
+          if (prep_next_mask) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xs + idx);
+            f32x4 kx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kx[e] = (d ? 1.f - mb[e] : mf[e]) * x[e];
+            *reinterpret_cast<f32x4*>(gs + idx) = kx;
+          }
+        } else {
+          // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd); keep mask per direction and sub-update
+          const f32x4 x = *reinterpret_cast<const f32x4*>(xs + idx);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(vs + idx);
+          f32x4 xn, kx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float keep = sub == 0 ? (d ? 1.f - mb[e] : mf[e]) : (d ? mb[e] : 1.f - mf[e]);
+            const float s = (d ? -eps : eps) * S[e];
+            const float drift = eps * (fast_exp(eps * Q[e]) * v[e] + Tt[e]);
+            const float es_ = fast_exp(s);
+            const float upd = d ? es_ * (x[e] - drift) : x[e] * es_ + drift;
+            xn[e] = keep * x[e] + (1.f - keep) * upd;
+            ld += (1.f - keep) * s;
+            kx[e] = (1.f - keep) * xn[e];
+          }
+          *reinterpret_cast<f32x4*>(xs + idx) = xn;
+          // second sub-update follows: its keep mask is the complement (gauge_dynamics.py:434-437, :472-475)
+          if (prep_next_mask) *reinterpret_cast<f32x4*>(gs + idx) = kx;
+        }
       }
+      // row r's log-det share of this wave: lanes r, r + 16, r + 32, r + 48 (fixed order: bit-reproducible)
+      ld += __shfl_xor(ld, 16, 64);
+      ld += __shfl_xor(ld, 32, 64);
+      if (q == 0) ldw[wave * kFM + r] += ld;
       FT_ADD(5, t0);
     }
     {
@@ -615,12 +631,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     const int sf = step, sb = p.num_steps - 1 - step;       // gauge_dynamics.py:453-457
     const float af = two_pi * (float)sf / (float)p.num_steps, ab = two_pi * (float)sb / (float)p.num_steps;
     const float tcf = cosf(af), tsf = sinf(af), tcb = cosf(ab), tsb = sinf(ab);
-    float tcr[4], tsr[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      tcr[e] = dirr[e] ? tcb : tcf;
-      tsr[e] = dirr[e] ? tsb : tsf;
-    }
+    const float tcr = dirl ? tcb : tcf, tsr = dirl ? tsb : tsf;      // time encoding of this lane's row
     for (int i = tid; i < D; i += kFThreads) {
       skm[i] = p.masks[(size_t)sf * D + i];
       skm[D + i] = p.masks[(size_t)sb * D + i];
