@@ -55,47 +55,46 @@ __device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restri
   for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
 }
 
-// Three-deep ring of B fragments: chunk kc+3 is requested as soon as chunk kc has been consumed, so every
-// load has two full MFMA blocks (~2 x 32 x NT cycles) to come back from L2.  The ring of the NEXT layer is
-// primed before the current layer's epilogue and barrier, which hides the pipeline fill.
-template <int NT>
+// DEPTH-deep ring of B fragments: chunk kc + DEPTH is requested as soon as chunk kc has been consumed, so every
+// load has DEPTH - 1 full MFMA blocks (32 x NT cycles each) to come back from L2 -- measured under this kernel's
+// load an L2 hit takes ~1,300 cycles, so 8-tile layers want DEPTH >= 3 and the 6-tile heads DEPTH >= 4.  The ring
+// of the NEXT layer is primed before the current layer's epilogue and barrier, which hides the pipeline fill.
+template <int NT, int DEPTH = 3>
 struct BRing {
-  f32x4 b[3][NT];
+  f32x4 b[DEPTH][NT];
 };
 
-template <int NT>
-__device__ __forceinline__ void ring_prime(BRing<NT>& R, const float* __restrict__ wp) {
-  load_frags<NT>(R.b[0], wp, 0);
-  load_frags<NT>(R.b[1], wp, 1);
-  load_frags<NT>(R.b[2], wp, 2);
+template <int NT, int DEPTH>
+__device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp) {
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) load_frags<NT>(R.b[s], wp, s);
 }
 
 // wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
 // (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
-template <int NT, int NKC, typename AF>
-__device__ __forceinline__ void stream_layer(BRing<NT>& R, const float* __restrict__ wp, AF afrag,
+template <int NT, int NKC, int DEPTH, typename AF>
+__device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wp, AF afrag,
                                              f32x4 (&acc)[NT]) {
-  static_assert(NKC >= 3, "ring depth");
-  f32x4 a0 = afrag(0), a1;
+  static_assert(NKC >= DEPTH, "ring depth");
+  f32x4 a0 = afrag(0);
   int kc = 0;
 #pragma nounroll
-  for (; kc + 3 <= NKC; kc += 3) {
-    a1 = afrag(kc + 1 < NKC ? kc + 1 : NKC - 1);
-    mfma_block<NT>(a0, R.b[0], acc);
-    if (kc + 3 < NKC) load_frags<NT>(R.b[0], wp, kc + 3);
-    a0 = afrag(kc + 2 < NKC ? kc + 2 : NKC - 1);
-    mfma_block<NT>(a1, R.b[1], acc);
-    if (kc + 4 < NKC) load_frags<NT>(R.b[1], wp, kc + 4);
-    a1 = afrag(kc + 3 < NKC ? kc + 3 : NKC - 1);
-    mfma_block<NT>(a0, R.b[2], acc);
-    if (kc + 5 < NKC) load_frags<NT>(R.b[2], wp, kc + 5);
+  for (; kc + DEPTH <= NKC; kc += DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const f32x4 a1 = afrag(kc + s + 1 < NKC ? kc + s + 1 : NKC - 1);
+      mfma_block<NT>(a0, R.b[s], acc);
+      if (kc + s + DEPTH < NKC) load_frags<NT>(R.b[s], wp, kc + s + DEPTH);
+      a0 = a1;
+    }
+  }
+  constexpr int REM = NKC % DEPTH;        // their fragments were requested by the last full round
+#pragma unroll
+  for (int s = 0; s < REM; ++s) {
+    const f32x4 a1 = afrag(NKC - REM + s + 1 < NKC ? NKC - REM + s + 1 : NKC - 1);
+    mfma_block<NT>(a0, R.b[s], acc);
     a0 = a1;
   }
-  if constexpr (NKC % 3 >= 1) {
-    if constexpr (NKC % 3 == 2) a1 = afrag(NKC - 1);
-    mfma_block<NT>(a0, R.b[0], acc);
-  }
-  if constexpr (NKC % 3 == 2) mfma_block<NT>(a1, R.b[1], acc);
 }
 
 }  // namespace l2hmc

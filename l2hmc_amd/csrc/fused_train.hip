@@ -283,17 +283,17 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       const float* wpb1 = pk + (size_t)wave * Cfg::KCO * NT1 * 256 + lane * 4;
       const float* wpb2 = pk + Cfg::P1 + (size_t)wave * Cfg::KCH * NT1 * 256 + lane * 4;
       const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KCH * NT3 * 256 + lane * 4;
-      BRing<NT1> R2;
+      BRing<NT1, 4> R2;
       {
-        BRing<NT1> R1;
-        ring_prime<NT1>(R1, wpb1);
+        BRing<NT1, 4> R1;
+        ring_prime<NT1, 4>(R1, wpb1);
         f32x4 acc[NT1];
 #pragma unroll
         for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* a = dos + r * SO + q * 4;
-        stream_layer<NT1, Cfg::KCO>(
+        stream_layer<NT1, Cfg::KCO, 4>(
             R1, wpb1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
-        ring_prime<NT1>(R2, wpb2);
+        ring_prime<NT1, 4>(R2, wpb2);
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {       // lane (q, r): row r, columns c0 .. c0 + 3 (fused_common.h)
           const int c0 = (wave * NT1 + t) * 16 + q * 4;
@@ -307,15 +307,15 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       tape_rows(is_v ? p.d2_v : p.d2_x, tcr0, d2s, H, SH);
 
       // ================= phase C: delta1 = (delta2 . Wh) gated by h1 > 0
-      BRing<NT3> R3;
+      BRing<NT3, 5> R3;
       {
         f32x4 acc[NT1];
 #pragma unroll
         for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* a = d2s + r * SH + q * 4;
-        stream_layer<NT1, Cfg::KCH>(
+        stream_layer<NT1, Cfg::KCH, 4>(
             R2, wpb2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
-        ring_prime<NT3>(R3, wpb3);
+        ring_prime<NT3, 5>(R3, wpb3);
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
           const int c0 = (wave * NT1 + t) * 16 + q * 4;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
 #pragma unroll
         for (int t = 0; t < NT3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* a = d1s + r * SH + q * 4;
-        stream_layer<NT3, Cfg::KCH>(
+        stream_layer<NT3, Cfg::KCH, 5>(
             R3, wpb3, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
 #pragma unroll
         for (int t = 0; t < NT3; ++t)

@@ -406,8 +406,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
     const float* wp2 = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
     const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
-    BRing<NT1> R2;
-    BRing<3 * NTH> R3;
+    constexpr int DP1 = 3, DP2 = 3, DPH = 4;      // ring depths (fused_common.h): first-layer halves, layer 2, heads
+    BRing<NT1, DP2> R2;
+    BRing<3 * NTH, DPH> R3;
     // ----- layer 1: two half-K streams (first input rows, then the second-input rows in gs)
     {
       constexpr int KH = Cfg::KC1 / 2;
@@ -437,34 +438,33 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
 #pragma unroll
         for (int t = 0; t < NT1; ++t) acc[t] = keep_v[t];
       } else {
-        BRing<NT1> RA, RB;
+        BRing<NT1, DP1> RA, RB;
         const float* wpb = wp1 + (size_t)KH * NT1 * 256;
+        ring_prime<NT1, DP1>(RB, wpb);          // both halves' first fragments are requested up front
         if (l1 == 4) {
-          ring_prime<NT1>(RB, wpb);
 #pragma unroll
           for (int t = 0; t < NT1; ++t) acc[t] = keep_x[t];
         } else {
-          ring_prime<NT1>(RA, wp1);
+          ring_prime<NT1, DP1>(RA, wp1);
 #pragma unroll
           for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
           const float* a1 = src1 + r * s1 + q * 4;
-          stream_layer<NT1, KH>(
+          stream_layer<NT1, KH, DP1>(
               RA, wp1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a1 + kc * 16); }, acc);
-          ring_prime<NT1>(RB, wpb);
           if (l1 == 3) {
 #pragma unroll
             for (int t = 0; t < NT1; ++t) keep_x[t] = acc[t];
           }
         }
         const float* a2 = src2 + r * s1 + q * 4;
-        stream_layer<NT1, KH>(
+        stream_layer<NT1, KH, DP1>(
             RB, wpb, [&](int kc) { return *reinterpret_cast<const f32x4*>(a2 + kc * 16); }, acc);
         if (l1 == 1) {
 #pragma unroll
           for (int t = 0; t < NT1; ++t) keep_v[t] = acc[t];
         }
       }
-      ring_prime<NT1>(R2, wp2);      // layer-2 weights start flowing under the epilogue + barrier
+      ring_prime<NT1, DP2>(R2, wp2);      // layer-2 weights start flowing under the epilogue + barrier
       FT_ADD(0, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -498,9 +498,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* a = h1 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
-      stream_layer<NT1, Cfg::KC2>(
+      stream_layer<NT1, Cfg::KC2, DP2>(
           R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
-      ring_prime<3 * NTH>(R3, wph);
+      ring_prime<3 * NTH, DPH>(R3, wph);
       FT_ADD(1, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       for (int t = 0; t < 3 * NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* a = h2 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
-      stream_layer<3 * NTH, Cfg::KC2>(
+      stream_layer<3 * NTH, Cfg::KC2, DPH>(
           R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
       FT_ADD(2, t0);
       t0 = FT_NOW();
