@@ -84,6 +84,15 @@ int l2hmc_kinetic_energy(const float* v, int64_t rows, int32_t D, float* out, l2
  *   coeff_s, coeff_q [D]  coeff_scale / coeff_transformation (exp applied on device)
  *   q_tanh: 0 = GenericNet/ConvNet3D (no tanh on transformation, quirk Q1),
  *           1 = utils/network.py `network` (ScaleTanh on F as well).
+ * Shapes (generic_net.py:20-93 accepts any x_dim / num_hidden):
+ *   - the layer-by-layer kernels (l2hmc_stq_dense, every l2hmc_gauge_* entry point) take ANY positive D, H, Ka, Kb
+ *     and any lattice T x X; widths that are multiples of 32 with 16-byte aligned rows take the staged 16-byte
+ *     loads, everything else (6x6: D = 72, H = 288; 3x5: D = 30) a bounds-checked instantiation of the same
+ *     kernels -- identical arithmetic, slower loads;
+ *   - the whole-trajectory kernels exist for D = 128 (T*X = 64, X a power of two): GenericNet H = 512 and
+ *     ConvNet3D F = 8 / H = 256; other shapes run layer by layer (l2hmc_dense_pack_bytes() == 0 says which);
+ *   - the TRAINING entry points (l2hmc_gauge_train_*) need D, H, Ka, Kb multiples of 32;
+ *   - ConvNet3D needs T and X multiples of 4 (two 2x2 poolings) and filter sizes (3,3,2), (2,2,2).
  * ------------------------------------------------------------------------ */
 typedef struct l2hmc_dense_net {
   int32_t D;   /* output width (x_dim) */
@@ -319,6 +328,11 @@ int l2hmc_adam_step(float* w, const float* g, float* m, float* v, int64_t n, flo
  * Target: mixture of K Gaussians (K=1, log_const ignored => plain Gaussian).
  *   energy(x) = -logsumexp_k( -0.5 (x-mu_k)^T P_k (x-mu_k) + log_const[k] ) / temperature
  * ------------------------------------------------------------------------ */
+/* Limits of this path (utils/network.py:89-114 takes any x_dim / num_nodes; the reference's own configurations are
+ * 2-D targets with num_nodes 10 (SCGExperiment.ipynb) and 50 (mog_model.py, network.py:89)): x_dim <= 8 with at most
+ * 8 mixture components (the closed-form energy, its gradient and Hessian-vector product live in registers), and
+ * num_nodes <= 64 (both networks' weights stay in LDS for the whole trajectory).  Larger values are refused with
+ * L2HMC_ERR_ARG; wider toy networks belong on the MFMA path above. */
 #define L2HMC_MAX_MIX 8
 #define L2HMC_MAX_SMALL_DIM 8
 typedef struct l2hmc_mog_target {

@@ -227,8 +227,7 @@ static int check_plan(const l2hmc_gauge_plan* p) {
     const l2hmc_dense_net* nets[2] = {&p->xnet, &p->vnet};
     for (const l2hmc_dense_net* n : nets) {
       L2HMC_REQUIRE(n->D == D, "plan: net D=%d != lattice x_dim=%d", n->D, D);
-      L2HMC_REQUIRE(dense_net_supported(n),
-                    "plan: net widths (Ka=%d, Kb=%d, H=%d) must be positive multiples of 32", n->Ka, n->Kb,
+      L2HMC_REQUIRE(dense_net_supported(n), "plan: net widths (Ka=%d, Kb=%d, H=%d) must be positive", n->Ka, n->Kb,
                     n->H);
       if (p->flags & L2HMC_PLAN_CONV3D) {
         const l2hmc_conv3d_front* f = (n == &p->xnet) ? &p->xfront : &p->vfront;
@@ -247,7 +246,6 @@ static int check_plan(const l2hmc_gauge_plan* p) {
                         n->coeff_q,
                     "plan: net has NULL weight pointer");
     }
-    L2HMC_REQUIRE(D % 4 == 0, "plan: x_dim must be a multiple of 4");
   }
   return L2HMC_OK;
 }
@@ -476,7 +474,7 @@ extern "C" int l2hmc_stq_dense(const l2hmc_dense_net* net, const float* a, const
                                size_t ws_bytes, l2hmc_stream_t stream) {
   L2HMC_REQUIRE(net != nullptr && rows >= 0, "stq_dense: bad arguments");
   if (rows == 0) return L2HMC_OK;
-  L2HMC_REQUIRE(dense_net_supported(net), "stq_dense: widths (Ka=%d, Kb=%d, H=%d) must be multiples of 32",
+  L2HMC_REQUIRE(dense_net_supported(net), "stq_dense: widths (D=%d, Ka=%d, Kb=%d, H=%d) must be positive", net->D,
                 net->Ka, net->Kb, net->H);
   L2HMC_REQUIRE(a && b && S && T && Q && ws, "stq_dense: NULL pointer");
   if (ws_bytes < l2hmc_stq_ws_bytes(rows, net->H)) {

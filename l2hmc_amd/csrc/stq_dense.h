@@ -107,6 +107,7 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream);
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
 int launch_heads(HeadsArgs& a, hipStream_t stream);
 int dense_net_supported(const l2hmc_dense_net* n);
+int dense_net_tileable(const l2hmc_dense_net* n);   // every width a multiple of 32 (fast staged loads)
 int fused_plan_supported(const l2hmc_gauge_plan* p);
 // Optional tape of the whole-trajectory kernel for the training path (train.hip): per network, every call's
 // first-layer input [a | b*mask], hidden activations, (S, T, Q) planes and the state the sub-update consumed,

@@ -50,7 +50,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // KIND 2: hidden layer (single source, plain bias)
 // KIND 3: backward-data through a relu layer: out = (A . Wt^T) where gate > 0, else 0   (no bias)
 // KIND 4: plain product out = A . Wt^T
-template <int BM, int KIND, int BK, int BN = 128>
+// RAGGED: any K, K1 and row strides (widths that are not multiples of 32, e.g. a 6x6 lattice: x_dim 72, H 288;
+// or rows that are not 16-byte aligned, x_dim 50): every staged element is loaded on its own under a bounds
+// check and the k-loop runs over ceil(K / BK) zero-padded tiles -- the same arithmetic (zeros add nothing), a
+// slower load path that only odd shapes take.
+template <int BM, int KIND, int BK, int BN = 128, bool RAGGED = false>
 __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int CPR = BK / 4;              // 16-byte chunks per staged row
   constexpr int LDK = BK + 4;              // rows of 36 / 68 floats: an odd number of 16-B slots => conflict-free b128 reads
@@ -103,7 +107,19 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     for (int i = 0; i < A_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (a_ok[i]) {
-        if (KIND == 2 || k0 < p.K1) {
+        if constexpr (RAGGED) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = k0 + a_kc[i] + j;
+            if (k < p.K1) {
+              v[j] = p.A1[(m0 + a_row[i]) * p.lda1 + k];
+            } else if (k < p.K) {
+              float t = p.A2[(m0 + a_row[i]) * p.lda2 + (k - p.K1)];
+              if (p.cmask_f) t *= (a_dir[i] ? p.cmask_b : p.cmask_f)[k - p.K1];
+              v[j] = t;
+            }
+          }
+        } else if (KIND == 2 || k0 < p.K1) {
           v = *reinterpret_cast<const f32x4*>(p.A1 + (m0 + a_row[i]) * p.lda1 + k0 + a_kc[i]);
         } else {
           const int kk = k0 - p.K1 + a_kc[i];
@@ -119,7 +135,17 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + b_row[i]) * p.K + k0 + b_kc[i]);
+      if (b_ok[i]) {
+        if constexpr (RAGGED) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = k0 + b_kc[i] + j;
+            if (k < p.K) v[j] = p.Wt[(int64_t)(n0 + b_row[i]) * p.K + k];
+          }
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + b_row[i]) * p.K + k0 + b_kc[i]);
+        }
+      }
       rb[i] = v;
     }
   };
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 // =====================================================================
 
 
-template <int BK>
+template <int BK, bool RAGGED = false>
 __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   constexpr int BM = 64, BNH = 32, NB = 3 * BNH;
   constexpr int CPR = BK / 4;
@@ -260,13 +286,29 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(p.A + (m0 + a_row[i]) * p.lda + k0 + a_kc[i]);
+      if (a_ok[i]) {
+        if constexpr (RAGGED) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k0 + a_kc[i] + j < p.K) v[j] = p.A[(m0 + a_row[i]) * p.lda + k0 + a_kc[i] + j];
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.A + (m0 + a_row[i]) * p.lda + k0 + a_kc[i]);
+        }
+      }
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(p.Wt + b_src[i] + k0 + b_kc[i]);
+      if (b_ok[i]) {
+        if constexpr (RAGGED) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k0 + b_kc[i] + j < p.K) v[j] = p.Wt[b_src[i] + k0 + b_kc[i] + j];
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.Wt + b_src[i] + k0 + b_kc[i]);
+        }
+      }
       rb[i] = v;
     }
   };
@@ -287,7 +329,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -408,22 +450,38 @@ static int check_ptr16(const void* p, const char* what) {
   return L2HMC_OK;
 }
 
-int dense_net_supported(const l2hmc_dense_net* n) {
-  return n->Ka > 0 && n->Kb > 0 && n->H > 0 && n->D > 0 && (n->Ka % BK) == 0 && (n->Kb % BK) == 0 &&
-         (n->H % BK) == 0;
+// any positive widths: multiples of 32 take the 16-byte staged loads, everything else the RAGGED instantiation
+int dense_net_supported(const l2hmc_dense_net* n) { return n->Ka > 0 && n->Kb > 0 && n->H > 0 && n->D > 0; }
+int dense_net_tileable(const l2hmc_dense_net* n) {
+  return dense_net_supported(n) && (n->Ka % BK) == 0 && (n->Kb % BK) == 0 && (n->H % BK) == 0;
 }
 
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
-  L2HMC_REQUIRE(a.K % BK == 0 && a.K1 % BK == 0 && a.K1 <= a.K, "gemm: K=%d K1=%d must be multiples of %d",
-                a.K, a.K1, BK);
-  L2HMC_REQUIRE(a.lda1 % 4 == 0 && (a.A2 == nullptr || a.lda2 % 4 == 0) && a.ldo > 0, "gemm: bad strides");
-  if (int e = check_ptr16(a.A1, "gemm A1")) return e;
-  if (a.K1 < a.K)
-    if (int e = check_ptr16(a.A2, "gemm A2")) return e;
-  if (int e = check_ptr16(a.Wt, "gemm W")) return e;
-  if (a.cmask_f) {
-    if (int e = check_ptr16(a.cmask_f, "gemm mask")) return e;
-    if (int e = check_ptr16(a.cmask_b, "gemm mask (bwd)")) return e;
+  L2HMC_REQUIRE(a.K > 0 && a.K1 >= 0 && a.K1 <= a.K && a.N > 0 && a.ldo > 0, "gemm: bad shape K=%d K1=%d N=%d", a.K,
+                a.K1, a.N);
+  L2HMC_REQUIRE(a.A1 && a.Wt && (a.K1 == a.K || a.A2), "gemm: NULL operand");
+  const bool ragged = a.K % BK != 0 || a.K1 % BK != 0 || a.lda1 % 4 != 0 || (a.A2 != nullptr && a.lda2 % 4 != 0) ||
+                      !aligned16(a.A1) || (a.K1 < a.K && !aligned16(a.A2)) || !aligned16(a.Wt) ||
+                      (a.cmask_f && (!aligned16(a.cmask_f) || !aligned16(a.cmask_b)));
+  if (ragged) {
+    a.ntiles = (int)ceil_div(a.N, 128);
+    a.mtiles = (int)ceil_div(a.rows, 64);
+    const dim3 grid(a.mtiles * a.ntiles);
+    const bool first1 = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr;
+    if (a.kind == 3) {
+      L2HMC_REQUIRE(a.gate != nullptr, "gemm: bad backward-data descriptor");
+      hipLaunchKernelGGL((gemm_relu_kernel<64, 3, 32, 128, true>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else if (a.kind == 4) {
+      hipLaunchKernelGGL((gemm_relu_kernel<64, 4, 32, 128, true>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else if (first1) {
+      hipLaunchKernelGGL((gemm_relu_kernel<64, 1, 32, 128, true>), grid, dim3(kGemmThreads), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((gemm_relu_kernel<64, 2, 32, 128, true>), grid, dim3(kGemmThreads), 0, stream, a);
+    }
+    L2HMC_CHECK_LAUNCH("gemm_relu (ragged)");
+    return L2HMC_OK;
   }
 #ifdef L2HMC_STAMPS
   a.stamps = (g_stamp_cls == ((a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr) ? 1 : 2)) ? g_stamp_buf : nullptr;
@@ -485,9 +543,16 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
 }
 
 int launch_heads(HeadsArgs& a, hipStream_t stream) {
-  L2HMC_REQUIRE(a.K % BK == 0 && a.lda % 4 == 0, "heads: K=%d must be a multiple of %d", a.K, BK);
-  if (int e = check_ptr16(a.A, "heads A")) return e;
-  if (int e = check_ptr16(a.Wt, "heads W")) return e;
+  L2HMC_REQUIRE(a.K > 0 && a.D > 0 && a.A && a.Wt, "heads: bad arguments");
+  const bool ragged = a.K % BK != 0 || a.lda % 4 != 0 || !aligned16(a.A) || !aligned16(a.Wt);
+  if (ragged) {
+    a.mtiles = (int)ceil_div(a.rows, 64);
+    a.ntiles = (int)ceil_div(a.D, 32);
+    L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
+    hipLaunchKernelGGL((heads_kernel<32, true>), dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+    L2HMC_CHECK_LAUNCH("heads (ragged)");
+    return L2HMC_OK;
+  }
 #ifdef L2HMC_STAMPS
   a.stamps = g_stamp_cls == 3 ? g_stamp_buf : nullptr;
 #endif

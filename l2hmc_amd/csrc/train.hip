@@ -792,7 +792,8 @@ static int check_train_plan(const l2hmc_gauge_plan* p) {
   for (int k = 0; k < 2; ++k) {
     const l2hmc_dense_net* n = nets[k];
     const int kin = conv ? conv3d_nflat(p->T, p->X, fronts[k]->F) : D;
-    L2HMC_REQUIRE(dense_net_supported(n) && n->D == D && n->Ka == kin && n->Kb == kin,
+    // the training kernels (taped forward, TN weight-gradient products, column sums) stage 32-wide k-tiles only
+    L2HMC_REQUIRE(dense_net_tileable(n) && n->D % 32 == 0 && n->D == D && n->Ka == kin && n->Kb == kin,
                   "train: network widths (D=%d Ka=%d Kb=%d H=%d) must be multiples of 32 with Ka = Kb = %d",
                   n->D, n->Ka, n->Kb, n->H, kin);
     if (conv) {

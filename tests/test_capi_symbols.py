@@ -59,11 +59,20 @@ def test_bad_arguments_are_rejected_on_the_host(L):
     assert L.l2hmc_lf_update_v(None, None, None, None, None, 0.1, 2, 4, 128, None, None, None) == 1
     with pytest.raises(ValueError):
         _lib.check(L.l2hmc_kinetic_energy(None, 3, 0, None, None))
-    # a net whose widths the MFMA path cannot tile is refused, not silently mis-computed
-    net = _lib.DenseNet(D=2, H=50, Ka=2, Kb=2)
+    # any positive widths are accepted by the layered kernels (odd ones take the bounds-checked instantiation);
+    # non-positive ones are refused, and a shape without a whole-trajectory kernel says so through pack_bytes
+    net = _lib.DenseNet(D=2, H=0, Ka=2, Kb=2)
     assert L.l2hmc_stq_dense(C.byref(net), None, None, None, 1.0, 0.0, 4, None, None, None, None, 0, None) == 1
-    assert b"multiples of 32" in L.l2hmc_last_error()
+    assert b"must be positive" in L.l2hmc_last_error()
+    net = _lib.DenseNet(D=72, H=288, Ka=72, Kb=72)
+    assert L.l2hmc_stq_dense(C.byref(net), None, None, None, 1.0, 0.0, 4, None, None, None, None, 0, None) == 1
+    assert b"NULL" in L.l2hmc_last_error()                    # the shape itself passed the check
     assert L.l2hmc_dense_pack_bytes(C.byref(net)) == 0
+    # training keeps the multiple-of-32 requirement
+    tplan = _lib.GaugePlan(T=6, X=6, num_steps=2, hmc=0, xnet=net, vnet=net, masks=16)   # any non-NULL address: host check only
+    assert L.l2hmc_gauge_train_forward(C.byref(tplan), 1.0, None, None, None, 4, None, None, None, None, None, 0,
+                                       None) == 1
+    assert b"multiples of 32" in L.l2hmc_last_error()
     plan = _lib.GaugePlan(T=8, X=8, num_steps=0, hmc=1)
     assert L.l2hmc_gauge_trajectory(C.byref(plan), 1.0, None, None, None, 4, None, None, None, None, None, 0,
                                     None) == 1

@@ -43,6 +43,7 @@ TOL_OP = 1e-5
 TOL_P = 2e-5
 MAX_RATIO, RMS_RATIO, P_RATIO = 4.5, 1.6, 6.0      # measured allowance over the fp32 oracle's own error (docstring)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H_REG = H.REGIMES
 
 
 def np_(t):
@@ -143,10 +144,51 @@ def test_stq_dense_matches_generic_net(la, regime, D, rows):
     assert np.abs(So).max() > (0.1 if regime == "stress" else 1e-3)      # the outputs are not trivially zero
 
 
-def test_stq_dense_rejects_untileable_widths(la):
-    net = la.GenericNet(model_name='XNet', x_dim=24, num_hidden=96, factor=2., name_scope='p', links_shape=(3, 4, 2))
-    with pytest.raises(ValueError, match="multiples of 32"):
-        net([np.zeros((4, 24)), np.zeros((4, 24)), np.array([[1., 0.]])])
+@pytest.mark.parametrize("D,H,rows", [(24, 96, 4), (72, 288, 70), (30, 120, 9), (50, 77, 131)])
+def test_stq_dense_any_width(la, D, H, rows):
+    """generic_net.py:20-93 takes any x_dim / num_hidden: widths that are not multiples of 32 (a 6x6 lattice has
+    x_dim 72, H 288) and rows that are not 16-byte aligned (x_dim 30, 50) run the RAGGED instantiation of the
+    layered kernels -- same arithmetic on zero-padded k-tiles."""
+    rng = np.random.default_rng(5)
+    p = onets.init_generic_net(np.random.default_rng(106), D, H, 2., **H_REG["stress"])
+    net = la.GenericNet(model_name='XNet', x_dim=D, num_hidden=H, factor=2., name_scope='position',
+                        links_shape=(1, D // 2, 2))
+    net.load_state(p)
+    a, b = rng.standard_normal((rows, D)), rng.uniform(0, 6.3, (rows, D))
+    t = np.array([[np.cos(0.7), np.sin(0.7)]])
+    S, T, Q = net([a, b, t])
+    f32 = lambda z: z.astype(np.float32).astype(np.float64)      # noqa: E731
+    p32 = {k: f32(v) for k, v in p.items()}
+    So, To, Qo = onets.generic_net(p32, [f32(a), f32(b), np.tile(f32(t), (rows, 1))])
+    assert H.relerr(np_(S), So) < TOL_OP and H.relerr(np_(T), To) < TOL_OP and H.relerr(np_(Q), Qo) < TOL_OP
+    assert np.abs(So).max() > 0.05
+
+
+@pytest.mark.parametrize("T,X", [(6, 6), (3, 5), (2, 4)])
+def test_dynamics_on_lattices_whose_widths_are_not_multiples_of_32(la, T, X):
+    """The whole operator surface on odd shapes (x_dim 72, 30, 16): leapfrog steps, both trajectories and
+    apply_transition against the oracle -- gauge_dynamics.py:169-187 builds num_hidden = 4 * x_dim for any lattice."""
+    N, eps, beta, B, D = 3, 0.15, 2.5, 11, 2 * T * X
+    xp, vp = H.gauge_weights(T, X, regime="stress")
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, D)
+    for step in (0, N - 1):
+        for fn, ofn in ((dyn._forward_lf, orc._forward_lf), (dyn._backward_lf, orc._backward_lf)):
+            x1, v1, ld = fn(x, v0f, beta, step)
+            ox, ov, old = ofn(x, v0f, beta, step)
+            assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP and H.relerr(np_(ld), old) < TOL_OP
+    want = orc.apply_transition(x, beta, v0f, v0b, coin, u)
+    for both in (True, False):
+        dyn.both_directions = both
+        got = [np_(g) for g in dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)]
+        assert H.relerr(got[0], want[0]) < 2 * TOL_OP and H.relerr(got[1], want[1]) < 2 * TOL_OP
+        assert np.abs(got[2] - want[2]).max() < TOL_P
+    smp = la.GaugeSampler(dyn)                       # native MCMC step on the same shape (general path)
+    xs = torch.as_tensor(x, dtype=torch.float32, device="cuda")
+    xn, px, obs, dq = smp.step(xs, beta)
+    assert xn.shape == xs.shape and float(xn.min()) >= 0 and torch.all((px >= 0) & (px <= 1))
+    assert H.relerr(np_(obs["action"]), olat.total_action(np_(xs), T, X)) < TOL_OP
 
 
 # ----------------------------------------------------------------- gauge dynamics
