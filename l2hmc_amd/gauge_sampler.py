@@ -127,6 +127,16 @@ class GaugeSampler:
         return out
 
 
+    @staticmethod
+    def run_dicts(out, beta):
+        """`run()` histories -> the four dicts the reference pickles per run (gauge_model.py:1409-1413, :1758-1822:
+        actions / plaqs / charges / charge_diff keyed by (step, beta)), for a caller that wants the reference's
+        in-memory layout; this package itself writes .npz (save_run)."""
+        n = out["px"].shape[0]
+        keys = [(i, beta) for i in range(n)]
+        return tuple({k: out[name][i] for i, k in enumerate(keys)}
+                     for name in ("actions", "plaqs", "charges", "charge_diff"))
+
     def save_run(self, out, out_dir, beta, therm_frac=10):
         """gauge_model.py:1758-2033 (`_save_run_info`) without pickles: the histories returned by `run` go to
         `observables_steps_{n}_beta_{beta}.npz` and a readable summary -- per-chain means and standard errors of

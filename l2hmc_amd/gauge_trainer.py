@@ -256,7 +256,8 @@ class GaugeTrainer:
         d = {"xnet": self._nets[0].flat_params()[0], "vnet": self._nets[1].flat_params()[0], "adam_m": self._m,
              "adam_v": self._v, "eps": self._eps_dev, "masks": self.dynamics.mask}
         out = {k: v.detach().cpu().numpy() for k, v in d.items()}
-        out.update(global_step=np.int64(self.global_step), adam_t=np.int64(getattr(self, "_adam_t", 0)),
+        out.update(global_step=np.int64(self.global_step), step=np.int64(self.global_step),
+                   adam_t=np.int64(getattr(self, "_adam_t", 0)),
                    lr=np.float64(self.learning_rate()), draws=np.int64(self.dynamics._draws))
         if samples is not None:
             out["samples"] = samples.detach().cpu().numpy() if isinstance(samples, torch.Tensor) else np.asarray(samples)
@@ -286,6 +287,24 @@ class GaugeTrainer:
             extra = {k: f[k] for k in ("samples", "beta") if k in f.files}
         self.sync_weights()
         return extra
+
+    def current_state(self, samples=None, beta=None):
+        """The reference's `_current_state` dict (gauge_model.py:370-376, :1190-1194) with its own keys --
+        {'samples', 'eps', 'step', 'beta', 'lr'} -- from this trainer; `save_state` writes the same keys (plus the
+        optimiser state the reference leaves to the TF checkpoint) into its .npz."""
+        import numpy as np
+        if isinstance(samples, torch.Tensor):
+            samples = samples.detach().cpu().numpy()
+        return {'samples': samples, 'eps': float(self.dynamics.eps), 'step': int(self.global_step),
+                'beta': None if beta is None else float(beta), 'lr': float(self.learning_rate() / self.world)}
+
+    @staticmethod
+    def train_data_dict(out, initial_step=0):
+        """`train()` histories -> the reference's `train_data_dict` (gauge_model.py:362-369, :1196-1205):
+        {'loss' | 'actions' | 'plaqs' | 'charges' | 'charge_diff' | 'accept_prob': {(step, beta): value}}."""
+        keys = [(initial_step + i, float(b)) for i, b in enumerate(out['beta'])]
+        return {name: {k: out[name][i] for i, k in enumerate(keys)}
+                for name in ('loss', 'actions', 'plaqs', 'charges', 'charge_diff', 'accept_prob')}
 
     def sync_weights(self):
         """Bring the reference-layout layer tensors (state_dict / save_weights) up to date."""

@@ -23,3 +23,28 @@ def integrated_time_direct(x, c=5):
     m = np.arange(len(taus)) < c * taus
     w = int(np.argmin(m)) if np.any(m) else len(taus) - 1
     return taus[w]
+
+
+def autocovariance_direct(X, tau=0):
+    """l2hmc/utils/func_utils.py:45-54: mean over t of sum_{chains,dims} x_t x_{t+tau} / n_chains (uncentred)."""
+    X = np.asarray(X, dtype=np.float64)
+    dT, dN, dX = X.shape
+    s = 0.
+    for t in range(dT - tau):
+        x1, x2 = X[t], X[t + tau]
+        s += np.sum(x1 * x2) / dN
+    return s / (dT - tau)
+
+
+def acl_spectrum_direct(X, scale):
+    """l2hmc/utils/func_utils.py:114-116: [autocovariance(X / scale, tau) for tau in range(n - 1)]."""
+    X = np.asarray(X, dtype=np.float64) / scale
+    return np.array([autocovariance_direct(X, t) for t in range(X.shape[0] - 1)])
+
+
+def autocorr_direct(x):
+    """l2hmc/utils/autocorr.py:36-40: np.correlate(x, x, 'full') / max, non-negative lags (no mean removal)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    full = np.array([np.dot(x[: n - k], x[k:]) for k in range(n)])
+    return full / full.max()

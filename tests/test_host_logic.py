@@ -309,3 +309,24 @@ def test_step_draw_counter_is_shared_and_never_reused():
             assert not (pair & used) and draws == 2 * d + 2
             used |= pair
     assert step_draw_index(0) == (0, 2) and step_draw_index(1) == (1, 4) and step_draw_index(2) == (1, 4)
+
+
+def test_reference_keyed_views_of_run_and_train_histories():
+    """the reference pickles dicts keyed by (step, beta) (gauge_model.py:1196-1205,
+    :1409-1413); the helpers re-key this package's array histories the same way."""
+    from l2hmc_amd.gauge_trainer import GaugeTrainer
+    from l2hmc_amd.gauge_sampler import GaugeSampler
+    steps, chains = 3, 4
+    out = {k: np.arange(steps * chains, dtype=np.float64).reshape(steps, chains) + i
+           for i, k in enumerate(("actions", "plaqs", "charges"))}
+    out.update(loss=np.array([1., 2., 3.]), accept_prob=np.array([.1, .2, .3]), charge_diff=np.array([0., 1., 0.]),
+               beta=np.array([2.0, 2.1, 2.2]))
+    d = GaugeTrainer.train_data_dict(out, initial_step=10)
+    assert set(d) == {'loss', 'actions', 'plaqs', 'charges', 'charge_diff', 'accept_prob'}
+    assert list(d['loss']) == [(10, 2.0), (11, 2.1), (12, 2.2)] and d['loss'][(11, 2.1)] == 2.0
+    np.testing.assert_array_equal(d['plaqs'][(12, 2.2)], out['plaqs'][2])
+    run = dict(px=np.zeros((steps, chains)), actions=out["actions"], plaqs=out["plaqs"], charges=out["charges"],
+               charge_diff=np.zeros((steps, chains)))
+    a, p, q, dq = GaugeSampler.run_dicts(run, 4.0)
+    assert list(a) == [(0, 4.0), (1, 4.0), (2, 4.0)]
+    np.testing.assert_array_equal(q[(1, 4.0)], out["charges"][1])
