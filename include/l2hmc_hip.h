@@ -302,6 +302,22 @@ int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const i
                                const l2hmc_dense_grads* gv, const l2hmc_conv3d_grads* gxf,
                                const l2hmc_conv3d_grads* gvf, float* deps, void* ws, size_t ws_bytes,
                                l2hmc_stream_t stream);
+/* The same pass with BUCKET NOTIFICATIONS for a data-parallel caller (gauge_model.py:942-943: Horovod's
+ * DistributedOptimizer all-reduces gradients tensor by tensor while the rest of the backward graph still runs).
+ * The weight gradients are finished in seven contiguous groups; as soon as everything that produces group b has
+ * been ENQUEUED on `stream`, `on_bucket(user, b)` runs on the calling host thread -- the caller records an event
+ * there and starts its collective for that group on another stream, so the exchange of group b overlaps the
+ * computation of group b + 1.  Groups, in the order they complete (k = 0: gx, k = 1: gv):
+ *   3k + 0: w1_t, wt, b1        3k + 1: wh_t, bh        3k + 2: whd_t, bhd, coeff_s, coeff_q
+ *   L2HMC_GRAD_BUCKET_REST (6): Conv3D front-end gradients (gxf, gvf) and deps -- always last.
+ * Results are identical to l2hmc_gauge_train_backward. */
+#define L2HMC_GRAD_BUCKET_REST 6
+typedef void (*l2hmc_bucket_fn)(void* user, int32_t bucket);
+int l2hmc_gauge_train_backward_buckets(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
+                                       float* dx, float* dv, const float* dlogdet, const l2hmc_dense_grads* gx,
+                                       const l2hmc_dense_grads* gv, const l2hmc_conv3d_grads* gxf,
+                                       const l2hmc_conv3d_grads* gvf, float* deps, void* ws, size_t ws_bytes,
+                                       l2hmc_stream_t stream, l2hmc_bucket_fn on_bucket, void* user);
 /* Loss (gauge_model.py:728-797) and its gradient with respect to the proposed states of the 2B stacked
  * chains (rows [0,B): started at x; rows [B,2B): started at z), through the accept probabilities
  * (gauge_dynamics.py:592-609).  x0, xN, vN: [2B][2*T*X]; p: [2B]; inv_count = 1 / (number of chains the

@@ -16,6 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
 PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY = 1, 2, 4
+GRAD_BUCKET_REST = 6
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 
 
 class DenseNet(C.Structure):
@@ -96,6 +98,10 @@ _PROTOS = {
     "l2hmc_gauge_train_backward": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _P, _P, _P,
                                              C.POINTER(DenseGrads), C.POINTER(DenseGrads),
                                              C.POINTER(Conv3DGrads), C.POINTER(Conv3DGrads), _P, _P, _SZ, _P]),
+    "l2hmc_gauge_train_backward_buckets": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _P, _P, _P,
+                                                     C.POINTER(DenseGrads), C.POINTER(DenseGrads),
+                                                     C.POINTER(Conv3DGrads), C.POINTER(Conv3DGrads), _P, _P, _SZ, _P,
+                                                     BUCKET_FN, _P]),
     "l2hmc_gauge_loss_backward": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _P, _P,
                                             _P, _P, _P]),
     "l2hmc_grad_sumsq": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P]),

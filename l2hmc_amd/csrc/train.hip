@@ -1027,11 +1027,12 @@ extern "C" int l2hmc_gauge_train_forward(const l2hmc_gauge_plan* plan, float bet
   return L2HMC_OK;
 }
 
-extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
-                                          float* dx, float* dv, const float* dlogdet,
-                                          const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv,
-                                          const l2hmc_conv3d_grads* gxf, const l2hmc_conv3d_grads* gvf, float* deps,
-                                          void* ws, size_t ws_bytes, l2hmc_stream_t stream) {
+static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
+                               float* dx, float* dv, const float* dlogdet,
+                               const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv,
+                               const l2hmc_conv3d_grads* gxf, const l2hmc_conv3d_grads* gvf, float* deps,
+                               void* ws, size_t ws_bytes, l2hmc_stream_t stream, l2hmc_bucket_fn on_bucket,
+                               void* user) {
   if (int e = check_train_plan(plan)) return e;
   L2HMC_REQUIRE(rows > 0 && dx && dv && dlogdet && gx && gv && deps && ws, "train_backward: bad arguments");
   const bool conv = (plan->flags & L2HMC_PLAN_CONV3D) != 0;
@@ -1153,17 +1154,23 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
     L2HMC_REQUIRE(g->w1_t && g->wt && g->b1 && g->wh_t && g->bh && g->whd_t && g->bhd && g->coeff_s && g->coeff_q,
                   "train_backward: NULL gradient pointer");
     const int Kin = nets[k]->Ka + nets[k]->Kb;
+    // three gradient buckets per network, each finished (weights, then the biases that go with them) before the
+    // next product starts, so a caller can put bucket b on the wire while bucket b + 1 is being computed:
+    //   3k + 0: [w1_t | wt | b1]      3k + 1: [wh_t | bh]      3k + 2: [whd_t | bhd | coeff_s | coeff_q]
     if (int e = gemm_tn(t.d1, H, conv ? t.feat : t.in, Kin, Rt, g->w1_t, w, s)) return e;
-    if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
-    if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
     if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
+    if (on_bucket) on_bucket(user, 3 * k + 0);
+    if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
     if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
+    if (on_bucket) on_bucket(user, 3 * k + 1);
+    if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
     if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcs_part,
                        (int)ncoef, (int64_t)D, g->coeff_s);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcq_part,
                        (int)ncoef, (int64_t)D, g->coeff_q);
     L2HMC_CHECK_LAUNCH("reduce_partials");
+    if (on_bucket) on_bucket(user, 3 * k + 2);
   }
   if (conv) {
     const l2hmc_conv3d_front* fr[2] = {&plan->xfront, &plan->vfront};
@@ -1192,7 +1199,27 @@ extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float be
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, w.eps_part, (int)ncoef, (int64_t)1, deps);
   L2HMC_CHECK_LAUNCH("reduce_partials");
+  if (on_bucket) on_bucket(user, L2HMC_GRAD_BUCKET_REST);
   return L2HMC_OK;
+}
+
+extern "C" int l2hmc_gauge_train_backward(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir, int64_t rows,
+                                          float* dx, float* dv, const float* dlogdet,
+                                          const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv,
+                                          const l2hmc_conv3d_grads* gxf, const l2hmc_conv3d_grads* gvf, float* deps,
+                                          void* ws, size_t ws_bytes, l2hmc_stream_t stream) {
+  return train_backward_impl(plan, beta, dir, rows, dx, dv, dlogdet, gx, gv, gxf, gvf, deps, ws, ws_bytes, stream,
+                             nullptr, nullptr);
+}
+
+extern "C" int l2hmc_gauge_train_backward_buckets(const l2hmc_gauge_plan* plan, float beta, const int32_t* dir,
+                                                  int64_t rows, float* dx, float* dv, const float* dlogdet,
+                                                  const l2hmc_dense_grads* gx, const l2hmc_dense_grads* gv,
+                                                  const l2hmc_conv3d_grads* gxf, const l2hmc_conv3d_grads* gvf,
+                                                  float* deps, void* ws, size_t ws_bytes, l2hmc_stream_t stream,
+                                                  l2hmc_bucket_fn on_bucket, void* user) {
+  return train_backward_impl(plan, beta, dir, rows, dx, dv, dlogdet, gx, gv, gxf, gvf, deps, ws, ws_bytes, stream,
+                             on_bucket, user);
 }
 
 extern "C" int l2hmc_gauge_loss_backward(int32_t T, int32_t X, float beta, const float* x0, const float* xN,

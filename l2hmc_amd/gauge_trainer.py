@@ -26,7 +26,8 @@ METRICS = {'l1': 0, 'l2': 1, 'cos': 2, 'cos2': 3, 'cos_diff': 4}
 class GaugeTrainer:
     def __init__(self, dynamics, lr_init=1e-3, lr_decay_steps=1000, lr_decay_rate=0.96, clip_value=None,
                  metric='cos_diff', loss_scale=1., aux_weight=1., std_weight=1., charge_weight=1., dist=None,
-                 allreduce_grads=True, beta1=0.9, beta2=0.999, epsilon=1e-8, eager_variables=False):
+                 allreduce_grads=True, beta1=0.9, beta2=0.999, epsilon=1e-8, eager_variables=False,
+                 bucketed=True):
         if metric not in METRICS:        # gauge_model.py:653-655
             raise AttributeError(f"metric={metric}. Expected one of: 'l1', 'l2', 'cos', 'cos2', or 'cos_diff'.")
         if dynamics.hmc:
@@ -44,6 +45,10 @@ class GaugeTrainer:
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist is not None else 1
         self.allreduce_grads = bool(allreduce_grads)
+        # bucketed: gradient groups go on the wire as soon as the reverse pass has produced them, on a side stream,
+        # while the next group's products still run (what hvd.DistributedOptimizer does tensor by tensor,
+        # gauge_model.py:942-943); False = one all-reduce of the whole buffer after the pass.  Same numbers.
+        self.bucketed = bool(bucketed)
         # Which variable list the optimiser sees.  Graph mode -- the path the CLI runs -- differentiates and
         # applies over `dynamics.variables` (gauge_model.py:825, :965-968), which holds the step size even when
         # it was created with trainable=False (gauge_dynamics.py:91-96): eps moves and counts in the clip norm
@@ -72,6 +77,26 @@ class GaugeTrainer:
             conv = [k for k in offsets if k not in net.SEGMENTS]
             self._conv_grad_structs.append(_lib.Conv3DGrads(**{k: at(k) for k in conv}) if conv else None)
             off += flat.numel()
+        self._buckets = self._bucket_ranges()
+        self._side = torch.cuda.Stream(device=dev) if (self.dist is not None and dev.type == "cuda") else None
+
+    def _bucket_ranges(self):
+        """{bucket id of l2hmc_gauge_train_backward_buckets: [(lo, hi), ...]} over the flat gradient buffer
+        [xnet | vnet | eps]; a network's flat layout is SEGMENTS (+ Conv3D kernels), so groups 3k .. 3k+2 are
+        single contiguous ranges and the rest (front-end gradients, eps) a few short ones."""
+        out, rest, off = {}, [], 0
+        for k, net in enumerate(self._nets):
+            flat, _, offsets = net.flat_params()
+            out[3 * k + 0] = [(off + offsets["w1_t"][0], off + offsets["b1"][1])]
+            out[3 * k + 1] = [(off + offsets["wh_t"][0], off + offsets["bh"][1])]
+            out[3 * k + 2] = [(off + offsets["whd_t"][0], off + offsets["coeff_q"][1])]
+            extra = [n for n in offsets if n not in net.SEGMENTS]
+            if extra:
+                rest.append((off + min(offsets[n][0] for n in extra), off + max(offsets[n][1] for n in extra)))
+            off += flat.numel()
+        rest.append((off, off + 1))
+        out[_lib.GRAD_BUCKET_REST] = rest
+        return out
 
     def broadcast_weights(self, src=0):
         """hvd.BroadcastGlobalVariablesHook(0) (gauge_model.py:1008): every rank starts from rank `src`'s
@@ -142,18 +167,46 @@ class GaugeTrainer:
                                                1.0 / (B * self.world), terms.data_ptr(), dxN.data_ptr(),
                                                dvN.data_ptr(), dld.data_ptr(), s))
         n0, n1 = self._sizes
-        _lib.check(L.l2hmc_gauge_train_backward(C.byref(plan), float(beta), dirs.data_ptr(), R, dxN.data_ptr(),
-                                                dvN.data_ptr(), dld.data_ptr(), C.byref(self._grad_structs[0]),
-                                                C.byref(self._grad_structs[1]),
-                                                *(C.byref(g) if g is not None else None
-                                                  for g in self._conv_grad_structs),
-                                                self.grads.data_ptr() + 4 * (n0 + n1), ws, nb, s))
+        bargs = (C.byref(plan), float(beta), dirs.data_ptr(), R, dxN.data_ptr(), dvN.data_ptr(), dld.data_ptr(),
+                 C.byref(self._grad_structs[0]), C.byref(self._grad_structs[1]),
+                 *(C.byref(g) if g is not None else None for g in self._conv_grad_structs),
+                 self.grads.data_ptr() + 4 * (n0 + n1), ws, nb, s)
         buf = torch.stack([terms.sum(dtype=torch.float32),
                            torch.full((), float(B), dtype=torch.float32, device=dev)])
-        if self.dist is not None:
+        if self.dist is not None and self.allreduce_grads and self.bucketed:
+            works, errors = [], []
+            cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+
+            def on_bucket(_user, b):           # host thread, right after bucket b's producers were enqueued
+                try:
+                    if self._side is not None:
+                        self._side.wait_stream(cur)
+                        with torch.cuda.stream(self._side):
+                            for lo, hi in self._buckets[int(b)]:
+                                works.append(self.dist.all_reduce(self.grads[lo:hi], op=self.dist.ReduceOp.SUM,
+                                                                  async_op=True))
+                    else:
+                        for lo, hi in self._buckets[int(b)]:
+                            works.append(self.dist.all_reduce(self.grads[lo:hi], op=self.dist.ReduceOp.SUM,
+                                                              async_op=True))
+                except Exception as e:          # noqa: BLE001 -- a ctypes callback cannot raise: re-raised below
+                    errors.append(e)
+            cb = _lib.BUCKET_FN(on_bucket)
+            _lib.check(L.l2hmc_gauge_train_backward_buckets(*bargs, cb, None))
+            if errors:
+                raise errors[0]
             self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
-            if self.allreduce_grads:
-                self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)
+            for wk in works:
+                wk.wait()
+            if self._side is not None:
+                cur.wait_stream(self._side)
+            self.last_bucket_count = len(works)
+        else:
+            _lib.check(L.l2hmc_gauge_train_backward(*bargs))
+            if self.dist is not None:
+                self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+                if self.allreduce_grads:
+                    self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)
         loss = buf[0] / buf[1]
         px = p[:B]
         x_prop = xN[:B]

@@ -43,12 +43,18 @@ def main():
         for net in (tr.dynamics.position_fn, tr.dynamics.momentum_fn):
             net.flat_params()[0].mul_(1.5)
         tr.dynamics.eps = tr.dynamics.eps * 2
-    tr = GaugeTrainer(tr.dynamics, dist=dist)
-    loss, *_ = tr.calc_loss_and_grads(x[lo:hi], 2.5, z=z[lo:hi], draws_x=tuple(a[lo:hi] for a in dx),
-                                      draws_z=tuple(a[lo:hi] for a in dz))
+    tr = GaugeTrainer(tr.dynamics, dist=dist)           # bucketed, overlapped all-reduce (the default)
+    assert tr.bucketed
+    shard = dict(z=z[lo:hi], draws_x=tuple(a[lo:hi] for a in dx), draws_z=tuple(a[lo:hi] for a in dz))
+    loss, *_ = tr.calc_loss_and_grads(x[lo:hi], 2.5, **shard)
+    assert tr.last_bucket_count == 7                    # 3 groups per network + (eps)
+    g_bucketed = tr.grads.cpu().numpy().copy()
+    tr.bucketed = False                                 # one all-reduce of the whole buffer after the pass
+    tr.calc_loss_and_grads(x[lo:hi], 2.5, **shard)
+    g_single = tr.grads.cpu().numpy().copy()
     tr.apply_gradients()
     if rank == 0:
-        np.savez(out, grads=tr.grads.cpu().numpy(), loss=float(loss), lr=tr.learning_rate(),
+        np.savez(out, grads=g_bucketed, grads_single=g_single, loss=float(loss), lr=tr.learning_rate(),
                  w=tr._nets[0].flat_params()[0].cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()

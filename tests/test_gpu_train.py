@@ -233,6 +233,9 @@ def test_data_parallel_gradients_equal_full_batch(tmp_path):
         assert p.wait(timeout=300) == 0
     with np.load(out) as f:
         got, got_loss, lr = f["grads"], float(f["loss"]), float(f["lr"])
+        # f2: the bucketed exchange (groups sent while later groups are still being computed) gives bit for bit
+        # what a single all-reduce of the whole buffer gives
+        np.testing.assert_array_equal(f["grads"], f["grads_single"])
     assert abs(got_loss - float(loss)) <= 1e-5 * max(1., abs(float(loss)))
     scale = np.abs(full).max()
     assert np.abs(got - full).max() <= 2e-5 * scale      # summation order differs between 1 and 2 shards
