@@ -183,6 +183,15 @@ def main():
     def step(x):
         return sampler.step(x, BETA)[0]
 
+    # untimed pre-warm, in ADDITION to the W warm-up steps: after the idle seconds of start-up the GPU clock takes
+    # ~20 ms of work to ramp (tools/warmup_probe.py -> profiles/r02_warmup_probe.txt: the first 10 steps after an
+    # idle period run 2.14 -> 1.70 ms, steady state 1.68), which a 5-step warm-up would leak into a 20-step timing
+    # (a FIXED count: every step carries a collective when sharded, so all ranks must run the same number)
+    prewarm = 150
+    for i in range(prewarm):
+        x = step(x)
+        if i % 16 == 15:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         x = step(x)
     torch.cuda.synchronize()
@@ -211,7 +220,7 @@ def main():
     out = {
         "metric": "leapfrog-steps/sec (whole node), 8x8 U(1) batch 2048, 10 LF",
         "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "warmup": args.warmup, "prewarm_steps_untimed": prewarm, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "U(1) 8x8 lattice, beta=2.0, batch 2048 per GPU, 10 LF steps, GenericNet H=512 "
                                "(BASELINE.json configs[2])",

@@ -66,11 +66,22 @@ enum ProfClass { kProfNone = 0, kProfGemmL1 = 1, kProfGemmL2 = 2, kProfHeads = 3
 void prof_before(int cls, hipStream_t stream);
 void prof_after(int cls, hipStream_t stream);
 
-// sum across the 64 lanes of a wave; every lane gets the total (fixed tree => deterministic)
+// sum across the 64 lanes of a wave; every lane gets the total (fixed order => deterministic).  Six DPP steps on
+// the VALU -- quad swaps, half-row and row mirrors, then the two row broadcasts that fold the four 16-lane rows into
+// lane 63 -- and one v_readlane: no LDS-crossbar traffic, where the __shfl_xor butterfly compiles to six dependent
+// ds_bpermute_b32 round trips (what kept the observable-producing stencil kernels at half the HBM rate).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {          // lanes of rows outside ROW_MASK receive 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_take<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf>(v);       // row_half_mirror
+  v += dpp_take<0x140, 0xf>(v);       // row_mirror: every lane holds its row's sum
+  v += dpp_take<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Philox4x32-10 (Salmon et al., SC'11) and the word -> float maps shared by every generator in the library
@@ -102,6 +113,30 @@ __device__ __forceinline__ void philox_normal4(const uint32_t c[4], float v[4]) 
     v[2 * h] = rad * cs;
     v[2 * h + 1] = rad * sn;
   }
+}
+
+// sin and cos of an angle in radians to ~1e-7 absolute (the accuracy of libm's sincosf, which the 1e-5 bar needs;
+// v_sin_f32 / v_cos_f32 alone are ~1e-6): Cody-Waite reduction by pi/2 in three parts, then the degree-7 / 8
+// minimax polynomials on [-pi/4, pi/4].  ~25 VALU instructions against ~110 for sincosf with its large-argument
+// path; the stencil kernels were VALU-bound on exactly that (profiles/r02_u1_*).  |x| >= 8192 (never reached by
+// wrapped links, possible for an arbitrary caller) falls back to libm.
+__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+  if (__builtin_expect(!(fabsf(x) < 8192.f), 0)) {
+    sincosf(x, sn, cs);
+    return;
+  }
+  const float n = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(n, -1.5703125f, x);
+  r = fmaf(n, -4.837512969970703125e-4f, r);
+  r = fmaf(n, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float s = fmaf(r * z, fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), r);
+  const float c = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                       fmaf(-0.5f, z, 1.f));
+  const int q = (int)n;
+  const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
 }
 
 // exp(min(dh, 0)) with the reference's NaN semantics: tf.minimum propagates NaN and

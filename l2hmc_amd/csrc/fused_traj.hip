@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
       const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
       float sn, cs;
-      sincosf(P, &sn, &cs);
+      fast_sincos(P, &sn, &cs);
       sp[fc * SP + s] = sn;
       act += 1.f - cs;
     }

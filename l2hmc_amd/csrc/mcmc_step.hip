@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void finish_step_kernel(const float* x, float*
   __syncthreads();
   const float Pin = xin.x - xin.y - xs[n_jp].x + xs[n_ip].y;
   float sn, cs;
-  sincosf(Pin, &sn, &cs);
+  fast_sincos(Pin, &sn, &cs);
   float a = wave_sum(1.f - cs), q = wave_sum(cs), ch = wave_sum(Pin - kTwoPiF * floorf((Pin + kPiF) * inv2pi));
   __syncthreads();
   // ... and the topological charge of the output for |dQ| (:718-725)

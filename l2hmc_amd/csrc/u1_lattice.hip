@@ -49,18 +49,22 @@ __global__ __launch_bounds__(kLatThreads) void u1_action_force_kernel(
   __syncthreads();
 
   const int work = nrow * sites;
+  // index arithmetic without run-time divisions where the shape allows it: one chain per workgroup (sites >= 256)
+  // has c = 0, and a power-of-two X turns site / X into a shift
+  const bool one_chain = cpw == 1;
+  const int xsh = (X & (X - 1)) == 0 ? 31 - __clz(X) : -1;
   float a_act = 0.f, a_plq = 0.f, a_chg = 0.f;
   for (int s = tid; s < work; s += kLatThreads) {
-    const int c = s / sites;
+    const int c = one_chain ? 0 : s / sites;
     const int site = s - c * sites;
-    const int i = site / X, j = site - i * X;
+    const int i = xsh >= 0 ? site >> xsh : site / X, j = site - i * X;
     const float* xc = xs + c * D;
     const int jp = (j + 1 == X) ? 0 : j + 1;
     const int ip = (i + 1 == T) ? 0 : i + 1;
     // gauge_model.py:676-679: x0[i,j] - x1[i,j] - x0[i,j+1] + x1[i+1,j]
     const float P = xc[2 * site] - xc[2 * site + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
     float sn, cs;
-    sincosf(P, &sn, &cs);
+    fast_sincos(P, &sn, &cs);
     sp[s] = sn;
     a_act += 1.f - cs;
     a_plq += cs;
@@ -113,9 +117,9 @@ __global__ __launch_bounds__(kLatThreads) void u1_action_force_kernel(
   if (force) {
     float2* dst = reinterpret_cast<float2*>(force + row0 * D);
     for (int s = tid; s < work; s += kLatThreads) {
-      const int c = s / sites;
+      const int c = one_chain ? 0 : s / sites;
       const int site = s - c * sites;
-      const int i = site / X, j = site - i * X;
+      const int i = xsh >= 0 ? site >> xsh : site / X, j = site - i * X;
       const float* spc = sp + c * sites;
       const int jm = (j == 0) ? X - 1 : j - 1;
       const int im = (i == 0) ? T - 1 : i - 1;
@@ -174,20 +178,20 @@ __global__ __launch_bounds__(kLatThreads) void u1_fast_kernel(
     __syncthreads();
     const float P = xv.x - xv.y - xs[buf][n_jp].x + xs[buf][n_ip].y;
     float sn, cs = 0.f;
-    if (SCALARS) sincosf(P, &sn, &cs);
-    else sn = sinf(P);
+    fast_sincos(P, &sn, &cs);
     sp[buf][tid] = sn;
     if (SCALARS) {
-      float a = wave_sum(1.f - cs), q = wave_sum(cs);
-      float ch = wave_sum(P - kTwoPi * floorf((P + kPi) * inv_two_pi));
+      // S = sum (1 - cos P) = sites - sum cos P: one reduction serves action and plaquette (the two differ by
+      // rounding of order 1e-7 relative; the kernel is VALU-bound once it produces observables)
+      const float q = wave_sum(cs);
+      const float ch = wave_sum(P - kTwoPi * floorf((P + kPi) * inv_two_pi));
       if (sites == kWave) {
         if ((tid & 63) == 0 && row < rows) {
-          if (action) action[row] = a;
+          if (action) action[row] = (float)sites - q;
           if (avg_plaq) avg_plaq[row] = q / (float)sites;
           if (top_charge) top_charge[row] = ch * inv_two_pi;
         }
       } else if ((tid & 63) == 0) {
-        red[tid >> 6][0] = a;
         red[tid >> 6][1] = q;
         red[tid >> 6][2] = ch;
       }
@@ -195,13 +199,12 @@ __global__ __launch_bounds__(kLatThreads) void u1_fast_kernel(
     __syncthreads();
     if (SCALARS && sites != kWave && site == 0 && row < rows) {
       const int w0 = base / kWave, nw = sites / kWave;
-      float a = 0.f, q = 0.f, ch = 0.f;
+      float q = 0.f, ch = 0.f;
       for (int w = 0; w < nw; ++w) {
-        a += red[w0 + w][0];
         q += red[w0 + w][1];
         ch += red[w0 + w][2];
       }
-      if (action) action[row] = a;
+      if (action) action[row] = (float)sites - q;
       if (avg_plaq) avg_plaq[row] = q / (float)sites;
       if (top_charge) top_charge[row] = ch * inv_two_pi;
     }

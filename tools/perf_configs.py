@@ -12,6 +12,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import l2hmc_amd as la  # noqa: E402
+if os.environ.get("L2HMC_LIB"):          # a diagnostic build (e.g. the previous commit's library, for before/after lines)
+    from l2hmc_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["L2HMC_LIB"])
 
 
 def timeit(fn, warm=2, iters=5):
@@ -69,26 +72,33 @@ def small_train(name, target, B, N, H):
 
 
 def u1_roofline():
+    """K3 standalone: HBM-bound stencil, 8*D bytes per chain (+ 4 per scalar observable)."""
     from l2hmc_amd import _lib
+    print("library:", _lib.LIB_PATH)
     for L, rows in ((8, 1 << 21), (16, 1 << 19), (32, 1 << 17)):
         D = 2 * L * L
         x = torch.rand(rows, D, device="cuda") * 6.28
         f = torch.empty_like(x)
-        a = torch.empty(rows, device="cuda")
+        a, pl, q = (torch.empty(rows, device="cuda") for _ in range(3))
         Lh = _lib.lib()
-
-        def run():
-            _lib.check(Lh.l2hmc_u1_action_force(x.data_ptr(), rows, L, L, 2.0, a.data_ptr(), f.data_ptr(), None, None,
-                                                _lib.stream_ptr()))
-        dt = timeit(run, warm=3, iters=10)
-        nbytes = rows * (8 * D + 4)
-        print(f"u1_action_force {L}x{L} rows={rows}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.0f} GB/s algorithmic "
-              f"({nbytes/dt/8e12:.2f} of 8 TB/s)", flush=True)
+        for what, ptrs, extra in (("force only (the integrator's call)", (None, f.data_ptr(), None, None), 0),
+                                  ("action + force", (a.data_ptr(), f.data_ptr(), None, None), 4),
+                                  ("action + plaquette + charge + force", (a.data_ptr(), f.data_ptr(), pl.data_ptr(),
+                                                                            q.data_ptr()), 12)):
+            def run():
+                _lib.check(Lh.l2hmc_u1_action_force(x.data_ptr(), rows, L, L, 2.0, *ptrs, _lib.stream_ptr()))
+            dt = timeit(run, warm=3, iters=10)
+            nbytes = rows * (8 * D + extra)
+            print(f"u1_action_force {L}x{L} rows={rows} {what:38s}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.0f} GB/s algorithmic "
+                  f"({nbytes/dt/8e12:.2f} of 8 TB/s)", flush=True)
         del x, f
 
 
 def main():
     print("device", torch.cuda.get_device_name(0), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "u1":
+        u1_roofline()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
         gauge("cfg4 U(1) 16x16 conv3D, B=1024/GPU, 15 LF", 16, 1024, 15, 0.2, 3.0, 'conv3D', iters=3)
         return
