@@ -154,6 +154,253 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs
   }
 }
 
+// =====================================================================================================
+// MFMA form of the same trajectory (the shipped path).  One WAVE integrates 16 chains and never exchanges anything
+// with another wave: lane (q = lane / 16, r = lane % 16) belongs to chain r of the wave.
+//   layer 1  (K = 2 dim + 2: far too thin for a matrix instruction) on the VALU: the lane evaluates the 4 * NT
+//            hidden units k(t, e) = 16 t + 4 q + e -- exactly the values it has to feed the next layer as ITS
+//            slice of the k dimension, so no transpose and no LDS row exchange exists at all;
+//   layer 2  v_mfma_f32_16x16x4_f32 with the WEIGHTS as the first operand (16 output units x 4 k) and the 16
+//            chains as the second: 16 chains x HP x HP is a dense tile with no padding beyond num_nodes -> HP;
+//            the product comes out as out[chain r][16 to + 4 q + e], again the lane's own k slice for the heads;
+//   heads    the same instruction, N = 3 dim (<= 16 per tile); S, T, Q reach the chain's four lanes through a
+//            1 KiB wave-private LDS patch (no barrier: LDS operations of one wave execute in order).
+// Weights sit in LDS in fragment order ([tile][k-step][lane]: one conflict-free ds_read_b32 per MFMA).  The
+// previous form (16 lanes per chain on the VALU, two workgroup barriers and HP broadcast LDS reads per network call)
+// spent its time in LDS issue and barriers: profiles/r02_small_traj_before_after.txt.
+// =====================================================================================================
+using f32x4s = __attribute__((ext_vector_type(4))) float;
+
+template <int HP, int MD>
+struct MfmaNet {
+  static constexpr int NT = HP / 16, KS = HP / 4, NTH = (3 * MD + 15) / 16, REC = 4 + 2 * MD;
+  static constexpr int rec = 0;                                 // [HP][REC]: b1, wt0, wt1, 0, W1a[MD], W1b[MD]
+  static constexpr int w2 = rec + HP * REC;                     // [NT][KS][64]
+  static constexpr int whd = w2 + NT * KS * 64;                 // [NTH][KS][64]
+  static constexpr int bh = whd + NTH * KS * 64;                // [HP]
+  static constexpr int bhd = bh + HP;                           // [NTH * 16]
+  static constexpr int es = bhd + NTH * 16;                     // [MD] (padded to 8)
+  static constexpr int eq = es + 8;
+  static constexpr int size = eq + 8;
+};
+
+template <int HP, int MD>
+__device__ void load_net_mfma(const l2hmc_dense_net& n, float* L, int dim) {
+  using V = MfmaNet<HP, MD>;
+  const int H = n.H, tid = threadIdx.x;
+  for (int i = tid; i < HP * V::REC; i += kSmallThreads) {
+    const int k = i / V::REC, f = i - k * V::REC;
+    float val = 0.f;
+    if (k < H) {
+      if (f == 0) val = n.b1[k];
+      else if (f == 1) val = n.wt[k];
+      else if (f == 2) val = n.wt[H + k];
+      else if (f >= 4 && f < 4 + MD) { if (f - 4 < dim) val = n.w1_t[(size_t)k * 2 * dim + (f - 4)]; }
+      else if (f >= 4 + MD) { if (f - 4 - MD < dim) val = n.w1_t[(size_t)k * 2 * dim + dim + (f - 4 - MD)]; }
+    }
+    L[V::rec + i] = val;
+  }
+  for (int i = tid; i < V::NT * V::KS * 64; i += kSmallThreads) {
+    const int lane = i & 63, s = (i >> 6) % V::KS, to = (i >> 6) / V::KS;
+    const int out = 16 * to + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+    L[V::w2 + i] = (out < H && k < H) ? n.wh_t[(size_t)out * H + k] : 0.f;
+  }
+  for (int i = tid; i < V::NTH * V::KS * 64; i += kSmallThreads) {
+    const int lane = i & 63, s = (i >> 6) % V::KS, th = (i >> 6) / V::KS;
+    const int o = 16 * th + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+    L[V::whd + i] = (o < 3 * dim && k < H) ? n.whd_t[(size_t)o * H + k] : 0.f;
+  }
+  for (int i = tid; i < HP; i += kSmallThreads) L[V::bh + i] = i < H ? n.bh[i] : 0.f;
+  for (int i = tid; i < V::NTH * 16; i += kSmallThreads) L[V::bhd + i] = i < 3 * dim ? n.bhd[i] : 0.f;
+  for (int i = tid; i < 8; i += kSmallThreads) {
+    L[V::es + i] = i < dim ? expf(n.coeff_s[i]) : 0.f;
+    L[V::eq + i] = i < dim ? expf(n.coeff_q[i]) : 0.f;
+  }
+}
+
+// (S, T, Q) = net([a, b, t]) for the 16 chains of this wave; every lane returns its own chain's values.
+template <int HP, int MD>
+__device__ __forceinline__ void net_eval_mfma(const float* L, int dim, int q_tanh, const float (&a)[MD],
+                                              const float (&b)[MD], float tc, float ts, int lane, float* scr,
+                                              float (&S)[MD], float (&T)[MD], float (&Q)[MD]) {
+  using V = MfmaNet<HP, MD>;
+  constexpr int NT = V::NT, KS = V::KS, NTH = V::NTH, REC = V::REC;
+  const int q = lane >> 4, r = lane & 15;
+  float h1[KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* rec = L + V::rec + (16 * t + 4 * q + e) * REC;
+      const f32x4s r0 = *reinterpret_cast<const f32x4s*>(rec);
+      float pre = r0[0] + (tc * r0[1] + ts * r0[2]);
+#pragma unroll
+      for (int d4 = 0; d4 < 2 * MD; d4 += 4) {
+        const f32x4s w = *reinterpret_cast<const f32x4s*>(rec + 4 + d4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = d4 + j;                        // c < MD: first input, else second (zero weights beyond dim)
+          pre += (c < MD ? a[c < MD ? c : 0] : b[c >= MD ? c - MD : 0]) * w[j];
+        }
+      }
+      h1[t * 4 + e] = fmaxf(pre, 0.f);
+    }
+  f32x4s acc[NT];
+#pragma unroll
+  for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
+  const float* w2 = L + V::w2 + lane;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int to = 0; to < NT; ++to)
+      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[(to * KS + s) * 64], h1[s], acc[to], 0, 0, 0);
+  float h2[KS];
+#pragma unroll
+  for (int to = 0; to < NT; ++to) {
+    const f32x4s bias = *reinterpret_cast<const f32x4s*>(L + V::bh + 16 * to + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h2[to * 4 + e] = fmaxf(acc[to][e] + bias[e], 0.f);
+  }
+  const float* wh = L + V::whd + lane;
+#pragma unroll
+  for (int th = 0; th < NTH; ++th) {
+    // two accumulators (even / odd k-steps): a single one would serialise on the 40-cycle dependent latency
+    f32x4s c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int s = 0; s < KS; s += 2) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[(th * KS + s) * 64], h2[s], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[(th * KS + s + 1) * 64], h2[s + 1], c1, 0, 0, 0);
+    }
+    const f32x4s bias = *reinterpret_cast<const f32x4s*>(L + V::bhd + 16 * th + 4 * q);
+    *reinterpret_cast<f32x4s*>(scr + r * (NTH * 16) + 16 * th + 4 * q) = c0 + c1 + bias;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* mine = scr + r * (NTH * 16);
+#pragma unroll
+  for (int d = 0; d < MD; ++d) {
+    if (d < dim) {
+      const float s_ = mine[d], t_ = mine[dim + d], q_ = mine[2 * dim + d];
+      S[d] = tanhf(s_) * L[V::es + d];
+      T[d] = t_;
+      Q[d] = (q_tanh ? tanhf(q_) : q_) * L[V::eq + d];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();          // the patch is free for the next call
+}
+
+template <int HP, int MD>
+__global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTrajArgs a) {
+  using V = MfmaNet<HP, MD>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const l2hmc_small_plan& P = a.plan;
+  const int dim = P.x_dim, N = P.trajectory_length;
+  const TargetView tv = target_view(P.target.dim, P.target.K);
+  float* Lx = lds;
+  float* Lv = Lx + V::size;
+  float* Lt = Lv + V::size;
+  float* Lm = Lt + tv.size;                       // masks [N][dim]
+  float* scr_all = Lm + ((N * dim + 3) & ~3);     // [waves][16 chains][NTH * 16]
+  if (!P.hmc) {
+    load_net_mfma<HP, MD>(P.xnet, Lx, dim);
+    load_net_mfma<HP, MD>(P.vnet, Lv, dim);
+  }
+  load_target(P.target, Lt);
+  for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
+  __syncthreads();                                // the only workgroup barrier of the kernel
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* scr = scr_all + wave * 16 * V::NTH * 16;
+  const int64_t r = ((int64_t)blockIdx.x * (kSmallThreads / 64) + wave) * 16 + (lane & 15);
+  const bool live = r < a.rows;
+  const int bwd = (a.dir && live) ? a.dir[r] : 0;
+  const float eps = P.eps;
+  const float inv_temp = 1.f / P.target.temperature;
+  const int isg = P.target.is_gaussian, K = P.target.K;
+
+  float x[MD], v[MD];
+#pragma unroll
+  for (int d = 0; d < MD; ++d) {
+    x[d] = (d < dim && live) ? a.x0[r * dim + d] : 0.f;
+    v[d] = (d < dim && live) ? a.v0[r * dim + d] : 0.f;
+  }
+  float g[MD], E0, E1;
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E0, g);
+  float kin0 = 0.f;
+#pragma unroll
+  for (int d = 0; d < MD; ++d) kin0 += v[d] * v[d];
+  const float H0 = E0 + 0.5f * kin0;
+
+  float logdet = 0.f;
+  float S[MD], T[MD], Q[MD], bin[MD];
+#pragma unroll
+  for (int d = 0; d < MD; ++d) S[d] = T[d] = Q[d] = 0.f;
+  for (int it = 0; it < N; ++it) {
+    const int step = bwd ? N - 1 - it : it;       // utils/dynamics.py:294-296
+    const float arg = 6.28318530717958647692f * (float)step / (float)N;
+    const float tc = cosf(arg), ts = sinf(arg);
+    const float* m = Lm + step * dim;
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+        for (int sub = 0; sub < 2; ++sub) {       // keep mask m then 1 - m (fwd) / 1 - m then m (bwd)
+          const bool keep_is_m = (sub == 0) != (bwd != 0);
+#pragma unroll
+          for (int d = 0; d < MD; ++d) {
+            const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
+            bin[d] = k * x[d];
+          }
+          if (!P.hmc) net_eval_mfma<HP, MD>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, scr, S, T, Q);
+#pragma unroll
+          for (int d = 0; d < MD; ++d) {
+            if (d < dim) {
+              const float k = keep_is_m ? m[d] : 1.f - m[d];
+              const float s = (bwd ? -eps : eps) * S[d];
+              const float drift = eps * (expf(eps * Q[d]) * v[d] + T[d]);
+              const float upd = bwd ? expf(s) * (x[d] - drift) : x[d] * expf(s) + drift;
+              x[d] = k * x[d] + (1.f - k) * upd;
+              logdet += (1.f - k) * s;
+            }
+          }
+        }
+        energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
+      }
+      if (!P.hmc) net_eval_mfma<HP, MD>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, scr, S, T, Q);
+#pragma unroll
+      for (int d = 0; d < MD; ++d) {
+        if (d < dim) {
+          const float s = (bwd ? -0.5f : 0.5f) * eps * S[d];
+          const float kick = 0.5f * eps * (expf(eps * Q[d]) * g[d] - T[d]);
+          v[d] = bwd ? expf(s) * (v[d] + kick) : v[d] * expf(s) - kick;
+          logdet += s;
+        }
+      }
+    }
+  }
+  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
+  float kin1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < MD; ++d) kin1 += v[d] * v[d];
+  const float H1 = E1 + 0.5f * kin1;
+  if (!live || lane >= 16) return;                 // the four lanes of a chain hold the same result
+#pragma unroll
+  for (int d = 0; d < MD; ++d) {
+    if (d < dim) {
+      a.x_out[r * dim + d] = x[d];
+      a.v_out[r * dim + d] = v[d];
+    }
+  }
+  if (a.sumlogdet) a.sumlogdet[r] = logdet;
+  if (a.p_accept) a.p_accept[r] = accept_from_delta(H0 - H1 + logdet);   // utils/dynamics.py:312-319
+}
+
+template <int HP, int MD>
+static size_t small_mfma_lds(int dim, int K, int N) {
+  return sizeof(float) * (2 * (size_t)MfmaNet<HP, MD>::size + target_view(dim, K).size + ((N * dim + 3) & ~3) +
+                          (size_t)(kSmallThreads / 64) * 16 * MfmaNet<HP, MD>::NTH * 16);
+}
+
 static int check_target(const l2hmc_mog_target* t) {
   L2HMC_REQUIRE(t != nullptr, "target is NULL");
   L2HMC_REQUIRE(t->dim > 0 && t->dim <= kMaxDim && t->K > 0 && t->K <= kMaxMix,
@@ -207,31 +454,32 @@ extern "C" int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float*
     HP = H <= 16 ? 16 : 64;
   }
   SmallTrajArgs a{*plan, x0, v0, dir, rows, x_out, v_out, sumlogdet, p_accept};
-  const size_t lds = sizeof(float) * (2 * (size_t)small_net_view(HP, dim).size +
-                                      target_view(dim, plan->target.K).size + ((N * dim + 3) & ~3) +
-                                      (size_t)HP * (kSmallThreads / kLPC));
+  const bool d2 = dim <= 2;          // the benchmark targets: x_dim 2 instance (chain state entirely in registers)
+  const int K = plan->target.K;
+  const size_t lds = d2 ? (HP == 16 ? small_mfma_lds<16, 2>(dim, K, N) : small_mfma_lds<64, 2>(dim, K, N))
+                        : (HP == 16 ? small_mfma_lds<16, kMaxDim>(dim, K, N) : small_mfma_lds<64, kMaxDim>(dim, K, N));
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
-  const dim3 grid((unsigned)ceil_div(rows, kSmallThreads / kLPC));
+  const dim3 grid((unsigned)ceil_div(rows, (kSmallThreads / 64) * 16));     // 16 chains per wave
   static DeviceOnce attr_once;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
   if (attr_once.pending()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<64, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<16, kMaxDim>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<16, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_kernel<64, kMaxDim>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<64, kMaxDim>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
   const dim3 blk(kSmallThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (dim <= 2) {       // the benchmark targets: x_dim 2 instance (chain state and S/T/Q entirely in registers)
-    if (HP == 16) hipLaunchKernelGGL((small_traj_kernel<16, 2>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((small_traj_kernel<64, 2>), grid, blk, lds, st, a);
+  if (d2) {
+    if (HP == 16) hipLaunchKernelGGL((small_traj_mfma_kernel<16, 2>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((small_traj_mfma_kernel<64, 2>), grid, blk, lds, st, a);
   } else {
-    if (HP == 16) hipLaunchKernelGGL((small_traj_kernel<16, kMaxDim>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((small_traj_kernel<64, kMaxDim>), grid, blk, lds, st, a);
+    if (HP == 16) hipLaunchKernelGGL((small_traj_mfma_kernel<16, kMaxDim>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((small_traj_mfma_kernel<64, kMaxDim>), grid, blk, lds, st, a);
   }
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;

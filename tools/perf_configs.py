@@ -99,6 +99,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "u1":
         u1_roofline()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        from l2hmc_amd import _lib
+        print("library:", _lib.LIB_PATH)
+        scg = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+        mog = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+        small("cfg1 SCG 2-D, B=128, 5 LF, H=10", scg, 128, 5, 10)
+        small("cfg2 MoG 2-D, B=4096, 10 LF, H=50", mog, 4096, 10, 50)
+        small("     MoG 2-D, B=65536, 10 LF, H=50 (chip-filling batch)", mog, 65536, 10, 50)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
         gauge("cfg4 U(1) 16x16 conv3D, B=1024/GPU, 15 LF", 16, 1024, 15, 0.2, 3.0, 'conv3D', iters=3)
         return
