@@ -6,14 +6,13 @@
 //   l2hmc/utils/network.py:89-114   (`network` MLP, ScaleTanh on S and F)
 //   l2hmc/utils/distributions.py:32-39,63-68,151-158 (energies; gradient by
 //   autodiff there, closed form here)
-// These configurations (x_dim 2, 10-50 hidden units) are launch/latency bound:
-// an MFMA tile would be >90 % padding, so the MLP runs on the VALU with both
-// networks' weights resident in LDS and the chain state in registers; x and v
-// are read once and written once per trajectory.  Sixteen lanes cooperate on a
-// chain: each owns HP/16 hidden units (first and hidden layer), the hidden
-// vector is exchanged through a 256-byte LDS row, and the heads are k-split
-// over the lanes and combined with a 16-lane xor-shuffle butterfly, so every
-// lane ends up with S, T, Q and applies the (cheap) update redundantly.
+// These configurations (x_dim 2, 10-50 hidden units) are launch/latency bound.
+// Both networks' weights stay in LDS and the chain state in registers; x and v
+// are read once and written once per trajectory.  A wave integrates 16 chains:
+// the thin first layer runs on the VALU, the hidden layer and the heads on
+// 16x16x4 fp32 MFMAs (see small_traj_mfma_kernel below).  The training kernel
+// (small_train.hip) keeps the earlier sixteen-lanes-per-chain VALU form of
+// small_mlp.h.
 #include "small_mlp.h"
 
 namespace l2hmc {
@@ -46,116 +45,8 @@ struct SmallTrajArgs {
   float* x_out; float* v_out; float* sumlogdet; float* p_accept;
 };
 
-template <int HP, int MD>
-__global__ __launch_bounds__(kSmallThreads) void small_traj_kernel(SmallTrajArgs a) {
-  constexpr int kMaxDim = MD;      // shadows the library-wide bound: register arrays / unrolled loops of this instance
-  extern __shared__ float lds[];
-  const l2hmc_small_plan& P = a.plan;
-  const int dim = P.x_dim, N = P.trajectory_length;
-  const SmallNetView nv = small_net_view(HP, dim);
-  const TargetView tv = target_view(P.target.dim, P.target.K);
-  float* Lx = lds;
-  float* Lv = Lx + nv.size;
-  float* Lt = Lv + nv.size;
-  float* Lm = Lt + tv.size;                       // masks [N][dim]
-  float* hx = Lm + ((N * dim + 3) & ~3);          // [16 chains][HP] hidden-vector exchange rows
-  if (!P.hmc) {
-    load_net<HP>(P.xnet, Lx, dim);
-    load_net<HP>(P.vnet, Lv, dim);
-  }
-  load_target(P.target, Lt);
-  for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
-  __syncthreads();
-
-  const int lsub = threadIdx.x & (kLPC - 1), slot = threadIdx.x / kLPC;   // lane within the chain
-  const int64_t r = (int64_t)blockIdx.x * (kSmallThreads / kLPC) + slot;
-  const bool live = r < a.rows;                   // dead chains still walk through the barriers
-  float* hrow = hx + slot * HP;
-  const int bwd = (a.dir && live) ? a.dir[r] : 0;
-  const float eps = P.eps;
-  const float inv_temp = 1.f / P.target.temperature;
-  const int isg = P.target.is_gaussian, K = P.target.K;
-
-  float x[kMaxDim], v[kMaxDim];
-#pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) {
-    x[d] = (d < dim && live) ? a.x0[r * dim + d] : 0.f;
-    v[d] = (d < dim && live) ? a.v0[r * dim + d] : 0.f;
-  }
-  float g[kMaxDim], E0, E1;
-  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E0, g);
-  float kin0 = 0.f;
-#pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) kin0 += v[d] * v[d];
-  const float H0 = E0 + 0.5f * kin0;
-
-  float logdet = 0.f;
-  float S[kMaxDim], T[kMaxDim], Q[kMaxDim], bin[kMaxDim];
-#pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) S[d] = T[d] = Q[d] = 0.f;
-  for (int it = 0; it < N; ++it) {
-    const int step = bwd ? N - 1 - it : it;       // utils/dynamics.py:294-296
-    const float arg = 6.28318530717958647692f * (float)step / (float)N;
-    const float tc = cosf(arg), ts = sinf(arg);
-    const float* m = Lm + step * dim;
-    for (int half = 0; half < 2; ++half) {
-      if (half == 1) {
-        // two position sub-updates; keep mask m then 1-m (fwd) / 1-m then m (bwd)
-        for (int sub = 0; sub < 2; ++sub) {
-          const bool keep_is_m = (sub == 0) != (bwd != 0);
-#pragma unroll
-          for (int d = 0; d < kMaxDim; ++d) {
-            const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
-            bin[d] = k * x[d];
-          }
-          if (!P.hmc) net_eval<HP, MD>(Lx, dim, P.xnet.q_tanh, v, bin, tc, ts, lsub, hrow, S, T, Q);
-#pragma unroll
-          for (int d = 0; d < kMaxDim; ++d) {
-            if (d < dim) {
-              const float k = keep_is_m ? m[d] : 1.f - m[d];
-              const float s = (bwd ? -eps : eps) * S[d];
-              const float drift = eps * (expf(eps * Q[d]) * v[d] + T[d]);
-              const float upd = bwd ? expf(s) * (x[d] - drift) : x[d] * expf(s) + drift;
-              x[d] = k * x[d] + (1.f - k) * upd;
-              logdet += (1.f - k) * s;
-            }
-          }
-        }
-        energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
-      }
-      if (!P.hmc) net_eval<HP, MD>(Lv, dim, P.vnet.q_tanh, x, g, tc, ts, lsub, hrow, S, T, Q);
-#pragma unroll
-      for (int d = 0; d < kMaxDim; ++d) {
-        if (d < dim) {
-          const float s = (bwd ? -0.5f : 0.5f) * eps * S[d];
-          const float kick = 0.5f * eps * (expf(eps * Q[d]) * g[d] - T[d]);
-          v[d] = bwd ? expf(s) * (v[d] + kick) : v[d] * expf(s) - kick;
-          logdet += s;
-        }
-      }
-    }
-  }
-  energy_grad<MD>(Lt, dim, K, isg, inv_temp, x, &E1, g);
-  float kin1 = 0.f;
-#pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) kin1 += v[d] * v[d];
-  const float H1 = E1 + 0.5f * kin1;
-  if (!live || lsub != 0) return;                  // every lane of the chain holds the same result
-#pragma unroll
-  for (int d = 0; d < kMaxDim; ++d) {
-    if (d < dim) {
-      a.x_out[r * dim + d] = x[d];
-      a.v_out[r * dim + d] = v[d];
-    }
-  }
-  if (a.sumlogdet) a.sumlogdet[r] = logdet;
-  if (a.p_accept) {
-    a.p_accept[r] = accept_from_delta(H0 - H1 + logdet);   // utils/dynamics.py:312-319
-  }
-}
-
 // =====================================================================================================
-// MFMA form of the same trajectory (the shipped path).  One WAVE integrates 16 chains and never exchanges anything
+// The trajectory kernel.  One WAVE integrates 16 chains and never exchanges anything
 // with another wave: lane (q = lane / 16, r = lane % 16) belongs to chain r of the wave.
 //   layer 1  (K = 2 dim + 2: far too thin for a matrix instruction) on the VALU: the lane evaluates the 4 * NT
 //            hidden units k(t, e) = 16 t + 4 q + e -- exactly the values it has to feed the next layer as ITS
