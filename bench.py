@@ -251,7 +251,8 @@ def main():
         Hd = HID_MULT * D
         per_class = {}
         # algorithmic FLOPs per launch: SURVEY.md 8 sizes table (8 x net MACs per chain-LF step)
-        for cls, name, flops in ((5, "gauge_traj_fused_kernel<128,512> (whole trajectory)",
+        for cls, name, flops in ((5, "gauge_traj_fused_kernel<128,512> (whole MCMC step in one launch: draws, both "
+                                     "trajectories, mix / MH, observables, wrap)",
                                   8.0 * net_macs(D, Hd) * rows * N_LF),
                                  (1, "gemm_relu_kernel<64,1> (first layer)", 2.0 * rows * Hd * 2 * D),
                                  (2, "gemm_relu_kernel<64,2> (hidden layer)", 2.0 * rows * Hd * Hd),
@@ -268,6 +269,26 @@ def main():
         stats.wait()
         per_class = {k: v for k, v in per_class.items() if v["launches"]}
         dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
+        # The step kernel also draws the momenta and finishes the step (mix, MH, observables, wrap).  The same kernel
+        # launched for the trajectories alone (l2hmc_gauge_trajectory: same rows, same FLOPs, no step prologue /
+        # epilogue) separates the integrator's MFMA efficiency from that fixed per-step work.
+        traj_only = None
+        if not args.layered:
+            x2 = torch.cat([x, x]).contiguous()
+            v2 = dyn._normal(tuple(x2.shape))
+            for _ in range(3):
+                dyn.transition_kernel(x2, BETA, forward=True, momentum=v2)
+            _lib.check(Lh.l2hmc_profile_begin(5))
+            for _ in range(20):
+                dyn.transition_kernel(x2, BETA, forward=True, momentum=v2)
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))
+            if n.value:
+                us = 1e3 * ms.value / n.value
+                tf = 8.0 * net_macs(D, Hd) * x2.shape[0] * N_LF / (us * 1e-6) / 1e12
+                traj_only = {"what": "the same kernel launched for the two trajectories alone (l2hmc_gauge_trajectory, "
+                                     f"{x2.shape[0]} rows x {N_LF} LF): no draws, no mix / MH / observables / wrap",
+                             "avg_launch_us": us, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS}
         # fabric-side bytes per launch of the fused kernel at this exact shape: read from the newest committed PMC
         # summary (tools/pmc_collect.sh + tools/pmc_summary.py -> profiles/rNN_pmc_fused_kernel.json); null if the
         # dominant kernel is another one or no summary is committed -- never a literal
@@ -280,7 +301,7 @@ def main():
                                            f"rocprofv3 --pmc passes ({traffic_src})",
                            "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
                            "algorithmic_flops_per_launch": dom["flops_per_launch"],
-                           "all_kernels": list(per_class.values()),
+                           "all_kernels": list(per_class.values()), "trajectory_only": traj_only,
                            "whole_step_tflops": (2 if both else 1) * BATCH * N_LF * 8 * net_macs(D, Hd)
                            / (dt / args.steps) / 1e12}
 

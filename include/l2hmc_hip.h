@@ -231,15 +231,18 @@ int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, const float
  * (seed, 2*draw+1) for coin | u -- reproducible with l2hmc_fill_normal/_uniform), both trajectories, mix,
  * accept/reject, then x <- mod(x_out, 2*pi) IN PLACE.  Per-chain outputs (any may be NULL): px = accept
  * probability; actions / plaqs / charges = observables of the step's INPUT samples (as :256-266);
- * charge_diff = |Q(x_in) - Q(x_out)| (:718-725).  Three launches when the plan has a fused kernel. */
+ * charge_diff = |Q(x_in) - Q(x_out)| (:718-725).  ONE launch when the plan has a whole-trajectory kernel: the
+ * kernel generates its own draws, a workgroup owns both directions of its chains and finishes the step in its
+ * epilogue (no intermediate ever reaches HBM); other plans run the same step through the public ops. */
 size_t l2hmc_gauge_mcmc_step_ws_bytes(const l2hmc_gauge_plan* plan, int64_t B);
 int l2hmc_gauge_mcmc_step(const l2hmc_gauge_plan* plan, float beta, float* x, int64_t B, uint64_t seed,
                           uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
                           float* charge_diff, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
 /* Same step, out of place (x_next may equal x_in) and with the per-step scalars the cross-shard reduce_mean of
  * gauge_model.py:795 needs: step_sums (FOUR floats, or NULL) = [sum p_accept, sum |dQ|, B, scratch] -- the first
- * three are what a rank all-reduces per accept/reject (fixed summation order; the fourth word is a ticket counter
- * the kernels use to find the last workgroup). */
+ * three are what a rank all-reduces per accept/reject (fixed summation order).  The fourth word is a ticket the
+ * one-launch step uses to find its last workgroup: it MUST BE 0 ON ENTRY and is left at 0, so a buffer zeroed once
+ * can be reused for every step. */
 int l2hmc_gauge_mcmc_step_ex(const l2hmc_gauge_plan* plan, float beta, const float* x_in, float* x_next, int64_t B,
                              uint64_t seed, uint64_t draw, float* px, float* actions, float* plaqs, float* charges,
                              float* charge_diff, float* step_sums, void* ws, size_t ws_bytes,

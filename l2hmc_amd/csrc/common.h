@@ -102,19 +102,6 @@ __device__ __forceinline__ float u01_open(uint32_t w) {   // (0, 1): 24 bits, ce
   return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
-// four standard normals from one Philox block (Box-Muller on word pairs)
-__device__ __forceinline__ void philox_normal4(const uint32_t c[4], float v[4]) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = u01_open(c[2 * h]), u2 = u01_open(c[2 * h + 1]);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincosf(6.28318530717958647692f * u2, &sn, &cs);
-    v[2 * h] = rad * cs;
-    v[2 * h + 1] = rad * sn;
-  }
-}
-
 // sin and cos of an angle in radians to ~1e-7 absolute (the accuracy of libm's sincosf, which the 1e-5 bar needs;
 // v_sin_f32 / v_cos_f32 alone are ~1e-6): Cody-Waite reduction by pi/2 in three parts, then the degree-7 / 8
 // minimax polynomials on [-pi/4, pi/4].  ~25 VALU instructions against ~110 for sincosf with its large-argument
@@ -137,6 +124,19 @@ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
   const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
   *sn = (q & 2) ? -a : a;
   *cs = ((q + 1) & 2) ? -b : b;
+}
+
+// four standard normals from one Philox block (Box-Muller on word pairs)
+__device__ __forceinline__ void philox_normal4(const uint32_t c[4], float v[4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = u01_open(c[2 * h]), u2 = u01_open(c[2 * h + 1]);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    fast_sincos(6.28318530717958647692f * u2, &sn, &cs);
+    v[2 * h] = rad * cs;
+    v[2 * h + 1] = rad * sn;
+  }
 }
 
 // exp(min(dh, 0)) with the reference's NaN semantics: tf.minimum propagates NaN and

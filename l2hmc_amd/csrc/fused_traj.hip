@@ -51,7 +51,8 @@ struct FusedCfg {
   static constexpr int CP1 = (CL / 2 + 1) * (CL / 2 + 1) * CF;              // pooled conv1 map, zero halo
   static constexpr int CONV_FLOATS = CONV ? 2 * kFM * SA + 4 * CW + kFM * (CXIN + CP1) : 0;
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
-                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/ + CONV_FLOATS;
+                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/ + 8 * kFM /*step mode*/ +
+                                    CONV_FLOATS;
 };
 
 // ---------------------------------------------------------------------------
@@ -126,6 +127,18 @@ struct FusedArgs {
   unsigned long long* stamps;            // diagnostic builds only
   int stagger;                           // cycles of start delay per in-XCD workgroup index (0 = none)
   FusedTape tx, tv;                      // training tape per network (all-NULL = sampling)
+  // Whole-MCMC-step mode (l2hmc_gauge_mcmc_step; step_x_next != NULL): the kernel draws its own momenta / coin /
+  // MH uniform (Philox streams (seed, 2 draw) and (seed, 2 draw + 1), bit-identical to l2hmc_fill_*), integrates,
+  // mixes, accepts, measures and wraps -- ONE launch per MCMC step.  A workgroup then owns 8 chains x both
+  // directions (rows 0-7 forward, 8-15 backward of the same chains) or, with step_both = 0, 16 chains in the
+  // direction their coin selects; x0 = the step's input samples [B][D], v0 / dir / x_out / v_out are unused.
+  float* step_x_next;                    // [B][D] wrapped output samples (may alias x0)
+  int64_t step_B;
+  unsigned long long step_seed, step_draw;
+  int step_both;
+  float* step_px; float* step_act; float* step_plq; float* step_chg; float* step_dq;   // [B] each, or NULL
+  float* step_sums;                      // [4] = [sum p, sum |dQ|, B, ticket] or NULL; ticket 0 on entry, left 0
+  float* step_part;                      // [2 * workgroups] scratch for the fixed-order sums
 };
 
 #ifdef L2HMC_STAMPS
@@ -152,8 +165,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   float* skm = sp + kFM * SP;              // [2][D]  masks of this step: forward row, backward row
   float* ldw = skm + 2 * D;                // [waves][16] log-det partial sums per wave
   int* sdir = reinterpret_cast<int*>(ldw + kFWaves * kFM);   // [16]
+  float* stp = reinterpret_cast<float*>(sdir + kFM);  // step mode: coin[16] u[16] p_row[16] obs[16][4]
   // ConvNet3D front-end state (CONV only; zero-sized otherwise)
-  float* fa = reinterpret_cast<float*>(sdir + kFM);   // [16][SA] features of the first input
+  float* fa = stp + 8 * kFM;                          // [16][SA] features of the first input
   float* fb = fa + kFM * SA;                          // [16][SA] features of the second input
   float* cwl = fb + kFM * SA;                         // [net x|v][input a|b][CW] filters
   float* cxin = cwl + 4 * Cfg::CW;                    // [16][CXIN] haloed chains
@@ -180,16 +194,57 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
   }
   // ---- stage chain state and constants ------------------------------------
-  for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
-    const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
-    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-    if (rr < nrow) {
-      const int64_t xr = p.x_mod > 0 ? (row0 + rr) % p.x_mod : row0 + rr;
-      xv = *reinterpret_cast<const f32x4*>(p.x0 + xr * D + c4);
-      vv = *reinterpret_cast<const f32x4*>(p.v0 + (row0 + rr) * D + c4);
+  const bool STEPM = p.step_x_next != nullptr;
+  const int cpw = STEPM ? (p.step_both ? kFM / 2 : kFM) : kFM;           // chains per workgroup in step mode
+  float* scoin = stp;                    // [16] direction coin per chain slot
+  float* su = stp + kFM;                 // [16] MH uniform
+  float* spx = stp + 2 * kFM;            // [16] accept probability per row
+  float* sobs = stp + 3 * kFM;           // [16][4] sum cos P (in), sum project P (in), sum project P (out), p
+  auto philox_u01 = [&](uint64_t elem, uint64_t stream) {        // element `elem` of l2hmc_fill_uniform's stream
+    const uint64_t b = elem >> 2;
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)(b >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox4x32_10(c, (uint32_t)p.step_seed, (uint32_t)(p.step_seed >> 32));
+    return (float)(c[elem & 3] >> 8) * (1.0f / 16777216.0f);
+  };
+  if (STEPM) {
+    if (tid < cpw) {
+      const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
+      const bool lv = chain < p.step_B;
+      scoin[tid] = lv ? philox_u01((uint64_t)chain, 2 * p.step_draw + 1) : 1.f;
+      su[tid] = lv ? philox_u01((uint64_t)(p.step_B + chain), 2 * p.step_draw + 1) : 1.f;
     }
-    *reinterpret_cast<f32x4*>(xs + rr * SX + c4) = xv;
-    *reinterpret_cast<f32x4*>(vs + rr * SX + c4) = vv;
+    __syncthreads();
+    for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
+      const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
+      const int k = p.step_both ? (rr & (kFM / 2 - 1)) : rr;
+      const int64_t chain = (int64_t)blockIdx.x * cpw + k;
+      const int dsel = p.step_both ? (rr >= kFM / 2 ? 1 : 0) : (scoin[k] > 0.5f ? 0 : 1);   // gauge_dynamics.py:221-227
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (chain < p.step_B) {
+        xv = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
+        // momentum of (direction dsel, chain): elements [(dsel * B + chain) * D, + D) of the normal stream
+        const uint64_t nb = (((uint64_t)dsel * (uint64_t)p.step_B + (uint64_t)chain) * D + c4) >> 2;
+        uint32_t c[4] = {(uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)(2 * p.step_draw), (uint32_t)((2 * p.step_draw) >> 32)};
+        philox4x32_10(c, (uint32_t)p.step_seed, (uint32_t)(p.step_seed >> 32));
+        float nv[4];
+        philox_normal4(c, nv);
+        vv = f32x4{nv[0], nv[1], nv[2], nv[3]};
+      }
+      *reinterpret_cast<f32x4*>(xs + rr * SX + c4) = xv;
+      *reinterpret_cast<f32x4*>(vs + rr * SX + c4) = vv;
+    }
+  } else {
+    for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
+      const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (rr < nrow) {
+        const int64_t xr = p.x_mod > 0 ? (row0 + rr) % p.x_mod : row0 + rr;
+        xv = *reinterpret_cast<const f32x4*>(p.x0 + xr * D + c4);
+        vv = *reinterpret_cast<const f32x4*>(p.v0 + (row0 + rr) * D + c4);
+      }
+      *reinterpret_cast<f32x4*>(xs + rr * SX + c4) = xv;
+      *reinterpret_cast<f32x4*>(vs + rr * SX + c4) = vv;
+    }
   }
   auto load_consts = [&](const l2hmc_dense_net& n, float* c) {
     for (int i = tid; i < H; i += kFThreads) {
@@ -225,7 +280,8 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   }
   if (tid < kFM) {
     int d = 0;
-    if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
+    if (STEPM) d = p.step_both ? (tid >= kFM / 2 ? 1 : 0) : (scoin[tid] > 0.5f ? 0 : 1);
+    else if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
     sdir[tid] = d;
   }
   if (tid < kFWaves * kFM) ldw[tid] = 0.f;
@@ -660,8 +716,151 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
   // ---- epilogue: energies, accept probability, write back -------------------------
   const float act1 = force_pass();
   const float kin1 = kinetic_pass();
+  if (STEPM) {
+    if (fl == 0) {
+      float sld = 0.f;
+#pragma unroll
+      for (int w = 0; w < kFWaves; ++w) sld += ldw[w * kFM + fc];
+      const double dh = (double)p.beta * ((double)act0 - (double)act1) + ((double)kin0 - (double)kin1) + (double)sld;
+      spx[fc] = accept_from_delta(dh);
+    }
+    __syncthreads();
+    // ---- mix the two directions, Metropolis-Hastings (gauge_dynamics.py:221-257, arithmetic kept as
+    //      mask * a + (1 - mask) * b); x_in -> gs rows, x_out -> h1 rows (both free now)
+    float* gin = gs;
+    float* gout = h1;
+    for (int i = tid; i < cpw * (D / 4); i += kFThreads) {
+      const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
+      const int64_t chain = (int64_t)blockIdx.x * cpw + k;
+      f32x4 xin = {0.f, 0.f, 0.f, 0.f};
+      if (chain < p.step_B) xin = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
+      f32x4 xp;
+      float pk;
+      if (p.step_both) {
+        const float fm = scoin[k] > 0.5f ? 1.f : 0.f, bm = 1.f - fm;
+        pk = fm * spx[k] + bm * spx[kFM / 2 + k];
+        const f32x4 xf = *reinterpret_cast<const f32x4*>(xs + k * SX + c4);
+        const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + (kFM / 2 + k) * SX + c4);
+        xp = fm * xf + bm * xb;
+      } else {
+        pk = spx[k];
+        xp = *reinterpret_cast<const f32x4*>(xs + k * SX + c4);
+      }
+      const float am = pk > su[k] ? 1.f : 0.f;                       // strict >, quirk Q5
+      const f32x4 xo = am * xp + (1.f - am) * xin;
+      *reinterpret_cast<f32x4*>(gin + k * SX + c4) = xin;
+      *reinterpret_cast<f32x4*>(gout + k * SX + c4) = xo;
+      if (c4 == 0) sobs[k * 4 + 3] = pk;
+    }
+    __syncthreads();
+    // ---- observables of the step's INPUT samples (gauge_model.py:256-266) and the charge of its output (:718-725)
+    auto plaq_sums = [&](const float* xc, float& scos, float& sproj) {
+      const float inv2pi = 0.15915494309189533577f;
+      float a = 0.f, b = 0.f;
+      for (int st = fl; st < sites; st += kTPC) {
+        const int i = st >> xsh, j = st & (X - 1);
+        const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
+        const float P = xc[2 * st] - xc[2 * st + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
+        float sn, cs;
+        fast_sincos(P, &sn, &cs);
+        a += cs;
+        b += P - 6.28318530717958647692f * floorf((P + 3.14159265358979323846f) * inv2pi);   // project_angle
+      }
+      scos = chain_sum(a);
+      sproj = chain_sum(b);
+    };
+    if (p.step_both) {
+      float a, b;
+      plaq_sums(fc < kFM / 2 ? gin + fc * SX : gout + (fc - kFM / 2) * SX, a, b);
+      if (fl == 0) {
+        if (fc < kFM / 2) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; }
+        else sobs[(fc - kFM / 2) * 4 + 2] = b;
+      }
+    } else {
+      float a, b, c_, d_;
+      plaq_sums(gin + fc * SX, a, b);
+      plaq_sums(gout + fc * SX, c_, d_);
+      if (fl == 0) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; sobs[fc * 4 + 2] = d_; }
+    }
+    __syncthreads();
+    const float inv2pi = 0.15915494309189533577f;
+    if (tid < cpw) {
+      const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
+      if (chain < p.step_B) {
+        const float q_in = sobs[tid * 4 + 1] * inv2pi, q_out = sobs[tid * 4 + 2] * inv2pi;
+        if (p.step_px) p.step_px[chain] = sobs[tid * 4 + 3];
+        if (p.step_act) p.step_act[chain] = (float)sites - sobs[tid * 4 + 0];      // sum (1 - cos P)
+        if (p.step_plq) p.step_plq[chain] = sobs[tid * 4 + 0] / (float)sites;
+        if (p.step_chg) p.step_chg[chain] = q_in;
+        if (p.step_dq) p.step_dq[chain] = fabsf(q_in - q_out);
+      }
+    }
+    if (p.step_sums) {
+      // [sum p_accept, sum |dQ|, chains] in a fixed order and without a further launch: every workgroup leaves its
+      // partial sums in step_part, the last one to arrive (ticket in step_sums[3]) adds them up and resets the ticket
+      int* last = reinterpret_cast<int*>(spx);            // spx is free again
+      if (tid == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < cpw; ++k) {
+          if ((int64_t)blockIdx.x * cpw + k < p.step_B) {
+            a0 += sobs[k * 4 + 3];
+            a1 += fabsf(sobs[k * 4 + 1] * inv2pi - sobs[k * 4 + 2] * inv2pi);
+          }
+        }
+        p.step_part[2 * blockIdx.x] = a0;
+        p.step_part[2 * blockIdx.x + 1] = a1;
+        __threadfence();
+        *last = atomicAdd(reinterpret_cast<int*>(p.step_sums + 3), 1) == (int)gridDim.x - 1;
+      }
+      __syncthreads();
+      if (*last) {
+        __threadfence();
+        float a0 = 0.f, a1 = 0.f;
+        for (int b = tid; b < (int)gridDim.x; b += kFThreads) {
+          a0 += p.step_part[2 * b];
+          a1 += p.step_part[2 * b + 1];
+        }
+        float* fin = vs;                                  // [2][kFThreads] scratch (vs is dead)
+        fin[tid] = a0;
+        fin[kFThreads + tid] = a1;
+        __syncthreads();
+        for (int st = kFThreads / 2; st > 0; st >>= 1) {
+          if (tid < st) {
+            fin[tid] += fin[tid + st];
+            fin[kFThreads + tid] += fin[kFThreads + tid + st];
+          }
+          __syncthreads();
+        }
+        if (tid == 0) {
+          p.step_sums[0] = fin[0];
+          p.step_sums[1] = fin[kFThreads];
+          p.step_sums[2] = (float)p.step_B;
+          *reinterpret_cast<int*>(p.step_sums + 3) = 0;
+        }
+      }
+    }
+    // ---- np.mod(x_out, 2 pi) (gauge_model.py:1388) and the write-back of the chains' new state
+    for (int i = tid; i < cpw * (D / 4); i += kFThreads) {
+      const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
+      const int64_t chain = (int64_t)blockIdx.x * cpw + k;
+      if (chain < p.step_B) {
+        f32x4 w = *reinterpret_cast<const f32x4*>(gout + k * SX + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tp = 6.28318530717958647692f;
+          float m_ = fmaf(-tp, floorf(w[e] * 0.15915494309189533577f), w[e]);       // w - 2 pi floor(w / 2 pi)
+          if (m_ < 0.f) m_ += tp;
+          if (m_ >= tp) m_ -= tp;
+          w[e] = m_;
+        }
+        *reinterpret_cast<f32x4*>(p.step_x_next + chain * D + c4) = w;
+      }
+    }
+    return;
+  }
   if (fl == 0 && fc < nrow) {
     float sld = 0.f;
+
 #pragma unroll
     for (int w = 0; w < kFWaves; ++w) sld += ldw[w * kFM + fc];      // fixed order: bit-reproducible
     const int64_t rr = row0 + fc;
@@ -781,6 +980,52 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(kFThreads), lds, stream, a);
   prof_after(kProfFused, stream);
   L2HMC_CHECK_LAUNCH("gauge_traj_fused");
+  return L2HMC_OK;
+}
+
+// One launch = one whole MCMC step of B chains (see FusedArgs::step_*).  part: 2 * ceil(B / cpw) floats of scratch.
+int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, float* x_next, int64_t B,
+                      uint64_t seed, uint64_t draw, int both, float* px, float* actions, float* plaqs, float* charges,
+                      float* dq, float* step_sums, float* part, hipStream_t stream) {
+  const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
+  using CfgG = FusedCfg<128, 512, 128, false>;
+  using CfgC = FusedCfg<128, 256, 64, true>;
+  static DeviceOnce step_once;
+  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : CfgG::LDS_FLOATS);
+  if (step_once.pending()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 256, 64, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * CfgC::LDS_FLOATS)) != hipSuccess) {
+      set_error("fused step: cannot reserve %zu B of LDS", lds);
+      return L2HMC_ERR_HIP;
+    }
+    step_once.done();
+  }
+  L2HMC_REQUIRE(x_in && x_next && B > 0 && (!step_sums || part), "fused step: bad arguments");
+  const int cpw = both ? kFM / 2 : kFM;
+  const int64_t nwg = ceil_div(B, cpw);
+  FusedArgs a{};
+  a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = 0; a.step_end = p->num_steps;
+  a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
+  a.xfront = p->xfront; a.vfront = p->vfront;
+  a.x0 = x_in; a.rows = nwg * kFM;
+  a.step_x_next = x_next; a.step_B = B; a.step_seed = seed; a.step_draw = draw; a.step_both = both;
+  a.step_px = px; a.step_act = actions; a.step_plq = plaqs; a.step_chg = charges; a.step_dq = dq;
+  a.step_sums = step_sums; a.step_part = part;
+#ifdef L2HMC_STAMPS
+  a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
+  a.stagger = g_fused_stagger;
+#endif
+  prof_before(kProfFused, stream);
+  if (conv)
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3((unsigned)nwg), dim3(kFThreads), lds, stream, a);
+  else
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3((unsigned)nwg), dim3(kFThreads), lds, stream, a);
+  prof_after(kProfFused, stream);
+  L2HMC_CHECK_LAUNCH("gauge_traj_fused (step)");
   return L2HMC_OK;
 }
 

@@ -19,6 +19,10 @@ class GaugeSampler:
         self.lattice = dynamics.lattice
         self.beta_init, self.beta_final, self.train_steps = beta_init, beta_final, train_steps
         self.stats = StepStats(dynamics._device, dist)
+        # [sum p, sum |dQ|, B, ticket] per step: the fused step kernel needs the ticket at 0 on entry and leaves it
+        # at 0, so the rows of one zero-initialised ring are handed out in turn (longer than StepStats' backlog)
+        self._sums_ring = torch.zeros(256, 4, dtype=torch.float32, device=dynamics._device)
+        self._sums_next = 0
 
     def update_beta(self, step):
         """gauge_model.py:1039-1046: linear annealing of 1/beta."""
@@ -44,7 +48,8 @@ class GaugeSampler:
         B = x.shape[0]
         outs = {k: torch.empty(B, dtype=torch.float32, device=x.device)
                 for k in ("px", "action", "avg_plaq", "top_charge", "dq")}
-        sums = torch.empty(4, dtype=torch.float32, device=x.device)     # [sum p, sum |dQ|, B, ticket], filled in-kernel
+        sums = self._sums_ring[self._sums_next]                  # [sum p, sum |dQ|, B, ticket], filled in-kernel
+        self._sums_next = (self._sums_next + 1) % self._sums_ring.shape[0]
         plan, L = dyn._plan(), _lib.lib()
         ws, nb = dyn._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
         # the step's random streams come from the dynamics' own draw counter (saved / restored with the state):
