@@ -343,7 +343,8 @@ def main():
         out["config"]["mog_cfg2"] = {
             "workload": "2-D mixture of Gaussians, 4096 chains per GPU, 10 LF steps, MLP H=50 (BASELINE.json configs[1])",
             "ms_per_propose": 1e3 * tmd, "chain_leapfrog_steps_per_s": world * 4096 * 10 / tmd,
-            "bound": "latency / VALU (x_dim 2, 50 hidden units: no MFMA tile fits; DESIGN.md K4)"}
+            "bound": "latency (a wave walks 40 dependent network calls for its 16 chains; hidden layer and heads on "
+                     "16x16x4 fp32 MFMAs, DESIGN.md K4)"}
     except Exception as e:                        # noqa: BLE001
         out["config"]["mog_cfg2"] = {"error": repr(e)}
 
