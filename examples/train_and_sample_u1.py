@@ -23,7 +23,9 @@ def main():
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     n_lf = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     eps0 = float(sys.argv[5]) if len(sys.argv) > 5 else 0.2
-    lr = float(sys.argv[6]) if len(sys.argv) > 6 else 1e-3
+    # 3e-4: from a HOT start the reference's default 1e-3 (globals.py:31, meant for its cold start) survives or
+    # diverges depending on the noise stream -- measured with two builds of the library, profiles/r02_example_*
+    lr = float(sys.argv[6]) if len(sys.argv) > 6 else 3e-4
     L, beta = 8, 2.0
     np.random.seed(42)
     lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=B, rand=True)

@@ -10,7 +10,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libl2hmc_hip.so")
+# L2HMC_LIB_PATH: load another build of the same ABI (diagnostic builds under tools/_diag); default = the in-tree library
+LIB_PATH = os.environ.get("L2HMC_LIB_PATH") or os.path.join(_HERE, "libl2hmc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
