@@ -408,7 +408,8 @@ int l2hmc_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, l2
  * Measurement aid (no reference counterpart): time every launch of one kernel
  * class with HIP events recorded on the launch stream.  begin() arms it (0
  * disarms), end() synchronises the recorded events and returns the summed
- * kernel time and launch count.  Not thread-safe; not for use while capturing.
+ * kernel time and launch count.  One process-wide recorder (mutex-protected; launches of concurrent threads are
+ * recorded one after the other); not for use while capturing a graph.
  *   1 = first dense layer   2 = hidden dense layer   3 = heads (+update)
  *   4 = u1_action_force     5 = fused whole-trajectory kernel
  * ------------------------------------------------------------------------ */

@@ -1,6 +1,7 @@
 // Error plumbing of the C ABI + the counter-based RNG.
 #include "common.h"
 #include <string.h>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -18,23 +19,32 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------
 // per-kernel-class event timing (host side only; never active unless asked)
 // ---------------------------------------------------------------------
-static int g_prof_cls = kProfNone;
+// One process-wide recorder (a measurement aid, documented as such in the header); a mutex keeps concurrent
+// launching threads from corrupting the event list -- the disarmed fast path is one relaxed atomic load.
+static std::atomic<int> g_prof_cls{kProfNone};
+static std::mutex g_prof_mu;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static size_t g_prof_used = 0;
+static thread_local bool g_prof_open = false;      // this thread recorded a start event that awaits its stop
 
 void prof_before(int cls, hipStream_t stream) {
-  if (cls != g_prof_cls) return;
+  if (cls != g_prof_cls.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_open = false;
   if (g_prof_used == g_prof_events.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     g_prof_events.emplace_back(a, b);
   }
   (void)hipEventRecord(g_prof_events[g_prof_used].first, stream);
+  g_prof_open = true;
 }
 
 void prof_after(int cls, hipStream_t stream) {
-  if (cls != g_prof_cls) return;
-  if (g_prof_used < g_prof_events.size()) (void)hipEventRecord(g_prof_events[g_prof_used++].second, stream);
+  if (cls != g_prof_cls.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_open && g_prof_used < g_prof_events.size()) (void)hipEventRecord(g_prof_events[g_prof_used++].second, stream);
+  g_prof_open = false;
 }
 
 // ---------------------------------------------------------------------
@@ -88,13 +98,15 @@ extern "C" const char* l2hmc_last_error(void) { return g_err; }
 extern "C" int l2hmc_profile_begin(int32_t kernel_class) {
   L2HMC_REQUIRE(kernel_class >= kProfNone && kernel_class <= kProfFused, "profile_begin: unknown class %d",
                 kernel_class);
-  g_prof_cls = kernel_class;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_cls.store(kernel_class, std::memory_order_relaxed);
   g_prof_used = 0;
   return L2HMC_OK;
 }
 
 extern "C" int l2hmc_profile_end(double* total_ms, int64_t* launches) {
-  g_prof_cls = kProfNone;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_cls.store(kProfNone, std::memory_order_relaxed);
   double tot = 0.0;
   for (size_t i = 0; i < g_prof_used; ++i) {
     float ms = 0.f;
