@@ -226,6 +226,14 @@ int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, const float
                            int32_t both_directions, float* x_prop, float* v_prop, float* p_accept,
                            float* x_out, void* ws, size_t ws_bytes, l2hmc_stream_t stream);
 
+/* apply_transition (gauge_dynamics.py:195-259) with the library's own draws -- Philox streams (seed, 2*draw) for the
+ * stacked momenta [v0_f; v0_b] and (seed, 2*draw+1) for coin | u, exactly the layout of l2hmc_gauge_mcmc_step,
+ * reproducible with l2hmc_fill_normal/_uniform -- instead of caller-provided ones: what `dynamics(x, beta)` is in
+ * the reference.  ONE launch for plans with a whole-trajectory kernel.  ws: l2hmc_gauge_mcmc_step_ws_bytes(plan, B). */
+int l2hmc_gauge_transition_draw(const l2hmc_gauge_plan* plan, float beta, const float* x, int64_t B, uint64_t seed,
+                                uint64_t draw, float* x_prop, float* v_prop, float* p_accept, float* x_out,
+                                void* ws, size_t ws_bytes, l2hmc_stream_t stream);
+
 /* One MCMC step of the sampling loop on device-resident chains (gauge_model.py:1371-1388 around
  * apply_transition): draws (Philox streams (seed, 2*draw) for the stacked momenta [v0_f; v0_b] and
  * (seed, 2*draw+1) for coin | u -- reproducible with l2hmc_fill_normal/_uniform), both trajectories, mix,

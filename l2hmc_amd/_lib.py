@@ -87,6 +87,8 @@ _PROTOS = {
     "l2hmc_gauge_transition_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64, _I32]),
     "l2hmc_gauge_transition": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _P, _P, _I64, _I32, _P, _P,
                                          _P, _P, _P, _SZ, _P]),
+    "l2hmc_gauge_transition_draw": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _U64, _U64, _P, _P, _P, _P, _P, _SZ,
+                                              _P]),
     "l2hmc_gauge_mcmc_step_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
     "l2hmc_gauge_mcmc_step": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _I64, _U64, _U64, _P, _P, _P, _P, _P, _P,
                                         _SZ, _P]),

@@ -127,13 +127,14 @@ struct FusedArgs {
   unsigned long long* stamps;            // diagnostic builds only
   int stagger;                           // cycles of start delay per in-XCD workgroup index (0 = none)
   FusedTape tx, tv;                      // training tape per network (all-NULL = sampling)
-  // Whole-MCMC-step mode (l2hmc_gauge_mcmc_step; step_x_next != NULL): the kernel draws its own momenta / coin /
+  // Whole-MCMC-step mode (l2hmc_gauge_mcmc_step, l2hmc_gauge_transition_draw; step_B > 0): the kernel draws its own momenta / coin /
   // MH uniform (Philox streams (seed, 2 draw) and (seed, 2 draw + 1), bit-identical to l2hmc_fill_*), integrates,
   // mixes, accepts, measures and wraps -- ONE launch per MCMC step.  A workgroup then owns 8 chains x both
   // directions (rows 0-7 forward, 8-15 backward of the same chains) or, with step_both = 0, 16 chains in the
   // direction their coin selects; x0 = the step's input samples [B][D], v0 / dir / x_out / v_out are unused.
-  float* step_x_next;                    // [B][D] wrapped output samples (may alias x0)
-  int64_t step_B;
+  float* step_x_next;                    // [B][D] wrapped output samples (may alias x0), or NULL
+  float* step_xprop; float* step_vprop; float* step_xout;   // [B][D] apply_transition's outputs (unwrapped), or NULL
+  int64_t step_B;                        // > 0 switches the mode on
   unsigned long long step_seed, step_draw;
   int step_both;
   float* step_px; float* step_act; float* step_plq; float* step_chg; float* step_dq;   // [B] each, or NULL
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
   }
   // ---- stage chain state and constants ------------------------------------
-  const bool STEPM = p.step_x_next != nullptr;
+  const bool STEPM = p.step_B > 0;
   const int cpw = STEPM ? (p.step_both ? kFM / 2 : kFM) : kFM;           // chains per workgroup in step mode
   float* scoin = stp;                    // [16] direction coin per chain slot
   float* su = stp + kFM;                 // [16] MH uniform
@@ -751,6 +752,18 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       *reinterpret_cast<f32x4*>(gin + k * SX + c4) = xin;
       *reinterpret_cast<f32x4*>(gout + k * SX + c4) = xo;
       if (c4 == 0) sobs[k * 4 + 3] = pk;
+      if (chain < p.step_B) {                                        // apply_transition's own outputs (:259)
+        if (p.step_xprop) *reinterpret_cast<f32x4*>(p.step_xprop + chain * D + c4) = xp;
+        if (p.step_xout) *reinterpret_cast<f32x4*>(p.step_xout + chain * D + c4) = xo;
+        if (p.step_vprop) {
+          f32x4 vp = *reinterpret_cast<const f32x4*>(vs + k * SX + c4);
+          if (p.step_both) {
+            const float fm = scoin[k] > 0.5f ? 1.f : 0.f, bm = 1.f - fm;
+            vp = fm * vp + bm * *reinterpret_cast<const f32x4*>(vs + (kFM / 2 + k) * SX + c4);
+          }
+          *reinterpret_cast<f32x4*>(p.step_vprop + chain * D + c4) = vp;
+        }
+      }
     }
     __syncthreads();
     // ---- observables of the step's INPUT samples (gauge_model.py:256-266) and the charge of its output (:718-725)
@@ -840,7 +853,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p
       }
     }
     // ---- np.mod(x_out, 2 pi) (gauge_model.py:1388) and the write-back of the chains' new state
-    for (int i = tid; i < cpw * (D / 4); i += kFThreads) {
+    for (int i = tid; p.step_x_next && i < cpw * (D / 4); i += kFThreads) {
       const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
       if (chain < p.step_B) {
@@ -986,7 +999,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
 // One launch = one whole MCMC step of B chains (see FusedArgs::step_*).  part: 2 * ceil(B / cpw) floats of scratch.
 int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, float* x_next, int64_t B,
                       uint64_t seed, uint64_t draw, int both, float* px, float* actions, float* plaqs, float* charges,
-                      float* dq, float* step_sums, float* part, hipStream_t stream) {
+                      float* dq, float* step_sums, float* part, hipStream_t stream, float* x_prop, float* v_prop,
+                      float* x_out) {
   const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   using CfgG = FusedCfg<128, 512, 128, false>;
   using CfgC = FusedCfg<128, 256, 64, true>;
@@ -1004,7 +1018,7 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
     }
     step_once.done();
   }
-  L2HMC_REQUIRE(x_in && x_next && B > 0 && (!step_sums || part), "fused step: bad arguments");
+  L2HMC_REQUIRE(x_in && (x_next || x_out) && B > 0 && (!step_sums || part), "fused step: bad arguments");
   const int cpw = both ? kFM / 2 : kFM;
   const int64_t nwg = ceil_div(B, cpw);
   FusedArgs a{};
@@ -1012,7 +1026,7 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
   a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
   a.xfront = p->xfront; a.vfront = p->vfront;
   a.x0 = x_in; a.rows = nwg * kFM;
-  a.step_x_next = x_next; a.step_B = B; a.step_seed = seed; a.step_draw = draw; a.step_both = both;
+  a.step_x_next = x_next; a.step_xprop = x_prop; a.step_vprop = v_prop; a.step_xout = x_out; a.step_B = B; a.step_seed = seed; a.step_draw = draw; a.step_both = both;
   a.step_px = px; a.step_act = actions; a.step_plq = plaqs; a.step_chg = charges; a.step_dq = dq;
   a.step_sums = step_sums; a.step_part = part;
 #ifdef L2HMC_STAMPS

@@ -151,3 +151,35 @@ extern "C" int l2hmc_gauge_mcmc_step_ex(const l2hmc_gauge_plan* plan, float beta
   }
   return l2hmc_wrap_angle(x_out, (int64_t)B * D, x_next, stream);
 }
+
+extern "C" int l2hmc_gauge_transition_draw(const l2hmc_gauge_plan* plan, float beta, const float* x, int64_t B,
+                                           uint64_t seed, uint64_t draw, float* x_prop, float* v_prop,
+                                           float* p_accept, float* x_out, void* ws, size_t ws_bytes,
+                                           l2hmc_stream_t stream) {
+  L2HMC_REQUIRE(plan != nullptr && B >= 0, "gauge_transition_draw: bad arguments");
+  if (B == 0) return L2HMC_OK;
+  L2HMC_REQUIRE(x && x_prop && v_prop && p_accept && x_out && ws, "gauge_transition_draw: NULL pointer");
+  const size_t need = l2hmc_gauge_mcmc_step_ws_bytes(plan, B);
+  if (ws_bytes < need) {
+    set_error("gauge_transition_draw: workspace %zu < %zu bytes", ws_bytes, need);
+    return L2HMC_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = 2 * plan->T * plan->X;
+  const bool selected = (plan->flags & L2HMC_PLAN_SELECTED_ONLY) != 0;
+  if (!(plan->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(plan))
+    return launch_fused_step(plan, beta, x, nullptr, B, seed, draw, selected ? 0 : 1, p_accept, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, s, x_prop, v_prop, x_out);
+  // other plans: the same draws into the workspace, then the public transition
+  char* base = static_cast<char*>(ws);
+  const size_t xv = align_up(sizeof(float) * (size_t)2 * B * D, 256);
+  float* Vw = reinterpret_cast<float*>(base + xv);
+  float* cu = reinterpret_cast<float*>(base + 2 * xv + align_up(sizeof(float) * (size_t)2 * B, 256));
+  const int64_t nblk = (((int64_t)2 * B * D + 3) >> 2) + ((2 * B + 3) >> 2);
+  hipLaunchKernelGGL(step_draws_kernel, dim3((unsigned)hmin(ceil_div(nblk, 256), 4096)), dim3(256), 0, s, Vw,
+                     (int64_t)2 * B * D, cu, 2 * B, seed, draw, nullptr);
+  L2HMC_CHECK_LAUNCH("step_draws");
+  char* rest = base + step_head_bytes(B, D);
+  return l2hmc_gauge_transition(plan, beta, x, Vw, Vw + (size_t)B * D, cu, cu + B, B, selected ? 0 : 1, x_prop, v_prop,
+                                p_accept, x_out, rest, ws_bytes - step_head_bytes(B, D), stream);
+}

@@ -129,7 +129,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
                             const FusedTape* tape_x = nullptr, const FusedTape* tape_v = nullptr);
 int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, float* x_next, int64_t B,
                       uint64_t seed, uint64_t draw, int both, float* px, float* actions, float* plaqs, float* charges,
-                      float* dq, float* step_sums, float* part, hipStream_t stream);
+                      float* dq, float* step_sums, float* part, hipStream_t stream, float* x_prop = nullptr,
+                      float* v_prop = nullptr, float* x_out = nullptr);
 // whole-trajectory reverse pass (fused_train.hip); deltas_*: {dout, d2, d1} tapes, coef_parts: {dcs_x, dcq_x, dcs_v, dcq_v}
 size_t fused_bwd_pack_floats(const l2hmc_dense_net* n);
 int fused_train_supported(const l2hmc_gauge_plan* p);

@@ -173,6 +173,20 @@ class GaugeDynamics:
         """:195-259 -> (position_post, momentum_post, accept_prob, position_out)."""
         x = self._x(position)
         B, D = x.shape
+        if momentum_f is None and momentum_b is None and coin is None and u is None:
+            # no draw injected: the library draws for itself (one stream pair from this object's counter, the
+            # layout of the native MCMC step) -- one kernel launch where the plan has a whole-trajectory kernel
+            x_prop, v_prop, x_out = (torch.empty_like(x) for _ in range(3))
+            p = torch.empty(B, dtype=torch.float32, device=x.device)
+            plan, L = self._plan(), _lib.lib()
+            ws, nb = self._ws.get(L.l2hmc_gauge_mcmc_step_ws_bytes(C.byref(plan), B), x.device)
+            draw, self._draws = _lib.step_draw_index(self._draws)
+            _lib.check(L.l2hmc_gauge_transition_draw(
+                C.byref(plan), float(beta), _lib.dev_ptr(x, name="position"), B, self._seed, draw, x_prop.data_ptr(),
+                v_prop.data_ptr(), p.data_ptr(), x_out.data_ptr(), ws, nb, _lib.stream_ptr(self._device)))
+            if self.check_numerics and not bool(torch.isfinite(x_prop).all() & torch.isfinite(v_prop).all()):
+                raise FloatingPointError("check_numerics: non-finite value in the proposed configuration")
+            return x_prop, v_prop, p, x_out
         v0f = self._x(momentum_f) if momentum_f is not None else self._normal((B, D))
         v0b = self._x(momentum_b) if momentum_b is not None else self._normal((B, D))
         coin = _lib.as_dev(coin, self._device) if coin is not None else self._uniform((B,))

@@ -955,10 +955,12 @@ def test_sampler_and_dynamics_share_one_draw_counter(la):
     assert not torch.equal(V, v_first)
     want = orc.apply_transition(np_(x), 2.0, np_(V[:B]), np_(V[B:]), *np.split(np_(_fill_u(dyn._seed, 3, 2 * B)), 2))
     assert np.abs(np_(a[1]) - want[2]).max() < 1e-4        # stream identity (another stream differs by O(1)); hot start
-    dyn.apply_transition(x, 2.0)                           # 4 single-stream draws
-    assert dyn._draws == 10
-    s1.step(x, 2.0)
-    assert dyn._draws == 12
+    dyn.apply_transition(x, 2.0)                           # no draw injected: one stream pair (6, 7)
+    assert dyn._draws == 8
+    dyn.apply_transition(x, 2.0, momentum_f=V[:B])         # partly injected: three single-stream draws
+    assert dyn._draws == 11
+    s1.step(x, 2.0)                                        # next even-aligned pair (12, 13)
+    assert dyn._draws == 14
 
 
 def _fill_u(seed, offset, n):
@@ -1093,3 +1095,33 @@ def test_chain_statistics_on_device_histories(la):
     got = stats.acl_spectrum(feats, 1.0)
     want = ostats.acl_spectrum_direct(feats.cpu().numpy().astype(np.float64), 1.0)
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("L,arch,B,both", [(8, "generic", 37, True), (8, "generic", 37, False), (8, "conv3D", 12, True),
+                                           (6, "generic", 9, True)])
+def test_dynamics_call_with_library_draws_matches_oracle(la, L, arch, B, both):
+    """`dynamics(x, beta)` as the reference calls it (gauge_model.py:753,844): no draw injected, so the library
+    draws for itself (l2hmc_gauge_transition_draw: one launch on plans with a whole-trajectory kernel).  The Philox
+    streams are reproducible through l2hmc_fill_*, so the oracle can be fed the very same draws."""
+    from l2hmc_amd import _lib
+    N, eps, beta, D = 3, 0.1, 2.0, 2 * L * L
+    xp, vp = (H.conv_weights if arch == "conv3D" else H.gauge_weights)(L, L, regime="mild")
+    orc = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch)
+    dyn = H.gauge_hip(L, L, N, eps, xp, vp, orc.mask, B, arch=arch, both_directions=both)
+    x0 = np.random.default_rng(3).uniform(0, 2 * np.pi, (B, D)).astype(np.float32)
+    dyn._draws = 5                                           # -> stream pair (6, 7)
+    got = [np_(g) for g in dyn(x0, beta)]
+    assert dyn._draws == 8
+    V = torch.empty(2 * B, D, device="cuda")
+    cu = torch.empty(2 * B, device="cuda")
+    _lib.check(_lib.lib().l2hmc_fill_normal(V.data_ptr(), V.numel(), dyn._seed, 6, None))
+    _lib.check(_lib.lib().l2hmc_fill_uniform(cu.data_ptr(), cu.numel(), dyn._seed, 7, None))
+    V, cu = np_(V), np_(cu)
+    want = orc.apply_transition(x0.astype(np.float64), beta, V[:B], V[B:], cu[:B], cu[B:])
+    assert H.relerr(got[0], want[0]) < 2 * TOL_OP and H.relerr(got[1], want[1]) < 2 * TOL_OP
+    assert np.abs(got[2] - want[2]).max() < TOL_P
+    safe = np.abs(want[2] - cu[B:]) > 1e-4
+    assert H.relerr(got[3][safe], want[3][safe]) < 2 * TOL_OP
+    acc = got[2] > cu[B:]
+    np.testing.assert_array_equal(got[3][acc & safe], got[0][acc & safe])
+    np.testing.assert_array_equal(got[3][~acc & safe], x0[~acc & safe])
