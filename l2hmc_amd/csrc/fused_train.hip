@@ -146,6 +146,32 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
     }
   };
 
+  // The tape of a call (S, T, Q, consumed state, both inputs: 12 x 16 bytes per thread) does not depend on anything
+  // this kernel computes, so the NEXT call's values are requested from HBM right after the current call's
+  // element-wise phase has consumed its own and travel under the three streamed products.
+  struct TapeRegs { f32x4 vS[2], vT[2], vQ[2], vst[2], va[2], vb[2]; };
+  auto load_tape = [&](int cidx_, bool is_v_, TapeRegs& t) {
+    const FusedTape& tp_ = is_v_ ? p.tv : p.tx;
+    const size_t plane = (size_t)p.rows * D;
+    const size_t tcr = (size_t)cidx_ * (size_t)p.rows + (size_t)row0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      t.vS[h] = t.vT[h] = t.vQ[h] = t.vst[h] = t.va[h] = t.vb[h] = z;
+      if (live) {
+        const float* sq = tp_.stq + (size_t)cidx_ * 3 * plane + ((size_t)row0 + fc) * D + c0 + 4 * h;
+        t.vS[h] = *reinterpret_cast<const f32x4*>(sq);
+        t.vT[h] = *reinterpret_cast<const f32x4*>(sq + plane);
+        t.vQ[h] = *reinterpret_cast<const f32x4*>(sq + 2 * plane);
+        t.vst[h] = *reinterpret_cast<const f32x4*>(tp_.st + (tcr + fc) * D + c0 + 4 * h);
+        t.va[h] = *reinterpret_cast<const f32x4*>(tp_.in + (tcr + fc) * (2 * D) + c0 + 4 * h);
+        t.vb[h] = *reinterpret_cast<const f32x4*>(tp_.in + (tcr + fc) * (2 * D) + D + c0 + 4 * h);
+      }
+    }
+  };
+  TapeRegs tnext;
+  load_tape(2 * (N - 1) + 1, true, tnext);          // the first call of the reverse pass: step N-1, call 3
+
   for (int step = N - 1; step >= 0; --step) {
     const int sf = step, sb = N - 1 - step;
     __syncthreads();
@@ -173,25 +199,18 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       // ================= phase A: the sub-update, element-wise (gauge_dynamics.py:486-590 differentiated)
       {
         float S[8], Tt[8], Q[8], st[8], ia[8], ib[8];
-        const size_t plane = (size_t)p.rows * D;
-        const size_t ro = (tcr0 + fc) * D + c0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          f32x4 vS = {0.f, 0.f, 0.f, 0.f}, vT = vS, vQ = vS, vst = vS, va = vS, vb = vS;
-          if (live) {
-            const float* sq = tp.stq + (size_t)cidx * 3 * plane + ((size_t)row0 + fc) * D + c0 + 4 * h;
-            vS = *reinterpret_cast<const f32x4*>(sq);
-            vT = *reinterpret_cast<const f32x4*>(sq + plane);
-            vQ = *reinterpret_cast<const f32x4*>(sq + 2 * plane);
-            vst = *reinterpret_cast<const f32x4*>(tp.st + ro + 4 * h);
-            va = *reinterpret_cast<const f32x4*>(tp.in + (tcr0 + fc) * (2 * D) + c0 + 4 * h);
-            vb = *reinterpret_cast<const f32x4*>(tp.in + (tcr0 + fc) * (2 * D) + D + c0 + 4 * h);
-          }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            S[4 * h + k] = vS[k]; Tt[4 * h + k] = vT[k]; Q[4 * h + k] = vQ[k];
-            st[4 * h + k] = vst[k]; ia[4 * h + k] = va[k]; ib[4 * h + k] = vb[k];
+            S[4 * h + k] = tnext.vS[h][k]; Tt[4 * h + k] = tnext.vT[h][k]; Q[4 * h + k] = tnext.vQ[h][k];
+            st[4 * h + k] = tnext.vst[h][k]; ia[4 * h + k] = tnext.va[h][k]; ib[4 * h + k] = tnext.vb[h][k];
           }
+        }
+        {
+          // request the next call's tape now (reverse order: calls 3, 2, 1, 0 of a step, then step - 1)
+          const int ncall = call == 0 ? 3 : call - 1, nstep = call == 0 ? step - 1 : step;
+          if (nstep >= 0) load_tape(2 * nstep + (ncall >= 2 ? 1 : 0), ncall == 0 || ncall == 3, tnext);
         }
         float o_s[8], o_t[8], o_q[8];
 #pragma unroll

@@ -1065,8 +1065,10 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
       }
     }
   }
-  {
-    // weights as the backward-data products read them (k = output unit contiguous), once per pass
+  const bool fused_bwd = fused_train_supported(plan);     // the forward call took the same branch and left the relu masks
+  if (!fused_bwd) {
+    // weights as the layered backward-data products read them (k = output unit contiguous), once per pass
+    // (the fused reverse pass packs its own fragment-ordered images instead)
     const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
     const NetTape* tapes[2] = {&w.x, &w.v};
     for (int k = 0; k < 2; ++k) {
@@ -1105,7 +1107,6 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
     L2HMC_CHECK_LAUNCH("update_bwd");
     return call_backward_data(plan, net, t, call, rows, w, s);
   };
-  const bool fused_bwd = fused_train_supported(plan);     // the forward call took the same branch and left the relu masks
   int64_t ncoef = nblk;            // workgroups that wrote coefficient / step-size partials
   if (fused_bwd) {
     // one launch for the whole reverse data path (fused_train.hip)
