@@ -31,11 +31,16 @@ namespace l2hmc {
 // features for ConvNet3D), CONV = the two inputs go through the conv front-end first (8x8 lattice, F = 8).
 template <int D, int H, int KA = D, bool CONV = false>
 struct FusedCfg {
+  // ConvNet3D plans run TWO waves per SIMD: their VALU conv stage is latency-bound at one (measured 0.987 -> 0.883 ms
+  // per step), while the GenericNet kernel, all MFMA streaming, is faster with one (1.655 against 1.745 ms)
+  static constexpr int WAVES = CONV ? 2 * kFWaves : kFWaves;
+  static constexpr int THREADS = 64 * WAVES;   // wave w owns output columns [w*N/WAVES, (w+1)*N/WAVES)
+  static constexpr int TPC = THREADS / kFM;    // threads per chain in the chain-local passes
   static constexpr int SX = D + 8;             // LDS row stride of x / v / second-input rows
   static constexpr int SA = KA + 8;            // LDS row stride of the conv feature rows
   static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
-  static constexpr int NT1 = H / (16 * kFWaves);   // 16-column tiles per wave, layers 1 and 2
-  static constexpr int NTH = D / (16 * kFWaves);   // tiles per wave per head
+  static constexpr int NT1 = H / (16 * WAVES);     // 16-column tiles per wave, layers 1 and 2
+  static constexpr int NTH = D / (16 * WAVES);     // tiles per wave per head
   static_assert(NT1 >= 1 && NT1 <= 8 && NTH >= 1, "every wave needs at least one tile per layer");
   static constexpr int KC1 = 2 * KA / 16;      // k-chunks (16 k each), layer 1
   static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
@@ -51,14 +56,15 @@ struct FusedCfg {
   static constexpr int CP1 = (CL / 2 + 1) * (CL / 2 + 1) * CF;              // pooled conv1 map, zero halo
   static constexpr int CONV_FLOATS = CONV ? 2 * kFM * SA + 4 * CW + kFM * (CXIN + CP1) : 0;
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
-                                    2 * D /*masks*/ + kFWaves * kFM /*ldw*/ + kFM /*dir*/ + 8 * kFM /*step mode*/ +
+                                    2 * D /*masks*/ + WAVES * kFM /*ldw*/ + kFM /*dir*/ + 8 * kFM /*step mode*/ +
                                     CONV_FLOATS;
 };
 
 // ---------------------------------------------------------------------------
 // weight packing (device side, once per weight update)
 // ---------------------------------------------------------------------------
-__global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out) {
+__global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out, int waves) {
+  const int kFWaves = waves;                 // waves per workgroup of the kernel that will read this image
   const int D = n.D, H = n.H, K1 = n.Ka + n.Kb;
   const size_t P1 = (size_t)K1 * H, P2 = (size_t)H * H, PH = (size_t)3 * D * H;
   const int NT1 = H / (16 * kFWaves), NTH = D / (16 * kFWaves);
@@ -149,8 +155,9 @@ extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; 
 
 // TAPE: training instantiation (GenericNet plans) that also writes the per-call tape of train.hip
 template <int D, int H, int KA, bool CONV, bool TAPE = false>
-__global__ __launch_bounds__(kFThreads) void gauge_traj_fused_kernel(FusedArgs p) {
+__global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_traj_fused_kernel(FusedArgs p) {
   using Cfg = FusedCfg<D, H, KA, CONV>;
+  constexpr int kFWaves = Cfg::WAVES, kFThreads = Cfg::THREADS, kTPC = Cfg::TPC;   // this instance's geometry
   constexpr int SX = Cfg::SX, SH = Cfg::SH, SA = Cfg::SA, NT1 = Cfg::NT1, NTH = Cfg::NTH;
   constexpr int sites = D / 2;
   constexpr int SP = sites + 4;
@@ -984,13 +991,13 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
   if (conv && tape)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true, true>), grid, dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true, true>), grid, dim3(CfgC::THREADS), lds, stream, a);
   else if (conv)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(CfgC::THREADS), lds, stream, a);
   else if (tape)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(CfgG::THREADS), lds, stream, a);
   else
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(CfgG::THREADS), lds, stream, a);
   prof_after(kProfFused, stream);
   L2HMC_CHECK_LAUNCH("gauge_traj_fused");
   return L2HMC_OK;
@@ -1035,9 +1042,9 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
 #endif
   prof_before(kProfFused, stream);
   if (conv)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3((unsigned)nwg), dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3((unsigned)nwg), dim3(CfgC::THREADS), lds, stream, a);
   else
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3((unsigned)nwg), dim3(kFThreads), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3((unsigned)nwg), dim3(CfgG::THREADS), lds, stream, a);
   prof_after(kProfFused, stream);
   L2HMC_CHECK_LAUNCH("gauge_traj_fused (step)");
   return L2HMC_OK;
@@ -1057,7 +1064,8 @@ extern "C" int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc
   L2HMC_REQUIRE(fused_net_supported(net), "dense_pack: shape (D=%d, H=%d, Ka=%d, Kb=%d) has no fused kernel",
                 net->D, net->H, net->Ka, net->Kb);
   L2HMC_REQUIRE(net->w1_t && net->wh_t && net->whd_t, "dense_pack: NULL weight pointer");
-  hipLaunchKernelGGL(pack_fused_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *net, packed);
+  const int waves = fused_conv_net(net) ? FusedCfg<128, 256, 64, true>::WAVES : FusedCfg<128, 512, 128, false>::WAVES;
+  hipLaunchKernelGGL(pack_fused_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *net, packed, waves);
   L2HMC_CHECK_LAUNCH("dense_pack");
   return L2HMC_OK;
 }

@@ -754,7 +754,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
                               conv3d_bwd_part_floats(fronts[k]->F))
                        : nullptr;
     t.bpack = take(fused_bwd_pack_floats(nets[k]));
-    t.gate = reinterpret_cast<unsigned*>(take((size_t)C * 2 * ceil_div(rows, 16) * 256));
+    t.gate = reinterpret_cast<unsigned*>(take((size_t)C * 2 * ceil_div(rows, 16) * 512));   // up to 512 threads per workgroup (ConvNet3D instance)
     t.w1_n = take((size_t)Kin * H);
     t.wh_n = take((size_t)H * H);
     t.whd_n = take((size_t)3 * D * H);
