@@ -16,10 +16,11 @@ def run(tag, N, eps, regime, steps, B):
     T = X = 8
     xp, vp = H.gauge_weights(T, X, regime=regime)
     orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    orc32 = H.gauge_oracle(T, X, N, eps, xp, vp, dtype=np.float32)     # the reference's own precision, same inputs
     dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
     rng = np.random.default_rng(11)
     x = rng.uniform(0, 2 * np.pi, (B, 128)).astype(np.float32)
-    ph, po, ah, ao = [], [], [], []
+    ph, po, ah, ao, pf = [], [], [], [], []
     t0 = time.time()
     for it in range(steps):
         v0f, v0b = rng.standard_normal((B, 128)), rng.standard_normal((B, 128))
@@ -28,10 +29,15 @@ def run(tag, N, eps, regime, steps, B):
         want = orc.apply_transition(x.astype(np.float64), 2.0, v0f, v0b, coin, u)
         p = got[2].cpu().numpy()
         ph.append(p); po.append(want[2]); ah.append(p > u); ao.append(want[2] > u)
+        pf.append(orc32.apply_transition(x, 2.0, v0f.astype(np.float32), v0b.astype(np.float32), coin,
+                                         u.astype(np.float32))[2].astype(np.float64))
         x = np.mod(got[3].cpu().numpy(), 2 * np.pi).astype(np.float32)
         if it % 200 == 0:
             print(f"  [{tag}] step {it} ({time.time() - t0:.0f} s)", flush=True)
-    ph, po = np.concatenate(ph), np.concatenate(po)
+    ph, po, pf = np.concatenate(ph), np.concatenate(po), np.concatenate(pf)
+    print(f"[{tag}] max |p - p_fp64| over all steps and chains: HIP {np.abs(ph - po).max():.2e}, float32 NumPy oracle "
+          f"(the reference's precision and op order) {np.abs(pf - po).max():.2e}; rms HIP "
+          f"{np.sqrt(np.mean((ph - po) ** 2)):.2e}, float32 oracle {np.sqrt(np.mean((pf - po) ** 2)):.2e}", flush=True)
     print(f"[{tag}: {N} LF, eps {eps}, '{regime}' weights, {steps} steps x {B} chains] mean accept probability "
           f"HIP {ph.mean():.6f}  oracle {po.mean():.6f}  (diff {abs(ph.mean() - po.mean()):.2e}); accepted fraction "
           f"HIP {np.mean(ah):.6f}  oracle {np.mean(ao):.6f}; max |p_hip - p_oracle| {np.abs(ph - po).max():.2e}; "
