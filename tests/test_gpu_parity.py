@@ -17,11 +17,16 @@ abs deviation relative to the tensor's own scale (>= 1).
         fused multiply-adds), <= 1.4 x for the log-det while that is < 1e-6;
       - RMS over a sample's elements: <= 1.0 x where it binds at cfg 3, worst
         single sample 1.47 x (cfg 4, 16 chains)       -> RMS_RATIO = 1.6;
+      - the 99.9 % quantile of the element-wise error (a tail statistic that is
+        not a single extreme value): worst single sample 2.09 x over ~250
+        trajectories of three configurations              -> Q999_RATIO = 2.5
+        (applied to samples of >= 4000 elements);
       - the MAX over a sample's ~10^4 chaotically amplified elements is an
         extreme value of a heavy-tailed distribution on both sides: the ratio of
-        the two maxima scatters (worst of 96 32-chain trajectories 4.08, typical
-        0.7-1.3; the libm-exp/tanh diagnostic build scatters the same, 5.08) ->
-        MAX_RATIO = 4.5 is an extreme-value allowance, not a precision one;
+        the two maxima scatters (worst single samples 4.08 and 4.61 in two runs
+        of 96 32-chain trajectories, typical 0.7-1.3; the libm-exp/tanh
+        diagnostic build scatters the same, 5.08)         -> MAX_RATIO = 6 is an
+        extreme-value allowance, not a precision one;
       - accept probability: a few chains per sample have p != 0, so the max
         ratio scatters most (typical <= 2.2)          -> P_RATIO = 6.
     Both apply only above the absolute bars (TOL_OP max, TOL_OP / 3 RMS, TOL_P):
@@ -41,7 +46,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_OP = 1e-5
 TOL_P = 2e-5
-MAX_RATIO, RMS_RATIO, P_RATIO = 4.5, 1.6, 6.0      # measured allowance over the fp32 oracle's own error (docstring)
+MAX_RATIO, Q999_RATIO, RMS_RATIO, P_RATIO = 6.0, 2.5, 1.6, 6.0     # measured allowances over the fp32 oracle's own error
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 H_REG = H.REGIMES
 
@@ -61,6 +66,11 @@ def assert_fp32_equivalent(got, want64, want32, what):
     erms, irms = rmserr(got, want64), rmserr(want32, want64)
     assert emax < max(TOL_OP, MAX_RATIO * imax), f"{what}: max err {emax:.2e} vs intrinsic fp32 {imax:.2e}"
     assert erms < max(TOL_OP / 3, RMS_RATIO * irms), f"{what}: rms err {erms:.2e} vs intrinsic fp32 {irms:.2e}"
+    if np.size(want64) >= 4000:
+        scale = max(1.0, np.max(np.abs(want64)))
+        eq = np.quantile(np.abs(np.asarray(got, dtype=np.float64) - want64), 0.999) / scale
+        iq = np.quantile(np.abs(np.asarray(want32, dtype=np.float64) - want64), 0.999) / scale
+        assert eq < max(TOL_OP / 2, Q999_RATIO * iq), f"{what}: 99.9 % quantile {eq:.2e} vs intrinsic fp32 {iq:.2e}"
 
 
 @pytest.fixture(scope="module")

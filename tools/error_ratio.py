@@ -50,6 +50,11 @@ def rms(got, want):
     return float(np.sqrt(np.mean((got - want) ** 2)) / max(1.0, np.max(np.abs(want))))
 
 
+def q999(got, want):
+    """99.9 % quantile of the element-wise error (a tail statistic that is not a single extreme value)."""
+    return float(np.quantile(np.abs(got - want), 0.999) / max(1.0, np.max(np.abs(want))))
+
+
 def np_(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
@@ -72,7 +77,7 @@ def main():
             dyn.fused = fused
             path = "fused" if fused else "layered"
             # accumulate over seeds and directions: per step, per quantity -> lists of (e_hip, e_f32)
-            acc = {(s, q, n): [] for s in range(N) for q in "xvl" for n in ("max", "rms")}
+            acc = {(s, q, n): [] for s in range(N) for q in "xvl" for n in ("max", "rms", "q999")}
             pacc, whole = [], []
             for seed in range(args.seeds):
                 x0, v0f, v0b, _, _ = H.gauge_inputs(B, D, seed=103 + 17 * seed)
@@ -91,6 +96,8 @@ def main():
                                            ("l", ld, t64[s][2], t32[s][2])):
                             acc[(s, q, "max")].append((rel(g, a), rel(b.astype(np.float64), a)))
                             acc[(s, q, "rms")].append((rms(g, a), rms(b.astype(np.float64), a)))
+                            if q != "l":
+                                acc[(s, q, "q999")].append((q999(g, a), q999(b.astype(np.float64), a)))
                     # the whole-trajectory launch (what sampling runs) must reproduce the stepwise result
                     xo, vo, p, sld = dyn.transition_kernel(x0, beta, forward=fwd, momentum=v0, return_logdet=True)
                     whole.append(max(rel(np_(xo), np_(x)), rel(np_(vo), np_(v))))
@@ -118,6 +125,9 @@ def main():
                         if any(a > 1e-5 / 3 for a, _ in acc[(s, q, "rms")]) else 0.0
                     worst[(regime, path, "max")] = max(worst.get((regime, path, "max"), 0.0), single)
                     worst[(regime, path, "rms")] = max(worst.get((regime, path, "rms"), 0.0), singler)
+                    if q != "l":
+                        sq = max([a / max(b, 1e-300) for a, b in acc[(s, q, "q999")] if a > 1e-5 / 2] or [0.0])
+                        worst[(regime, path, "q99.9")] = max(worst.get((regime, path, "q99.9"), 0.0), sq)
                 row.append("  " + " / ".join(f"{r:5.2f}" for r in rr))
                 print(" ".join(row))
             ph = np.mean([a for a, _, _, _ in pacc])
@@ -131,8 +141,8 @@ def main():
             worst[(regime, path, "p max")] = psingle
             worst[(regime, path, "p rms")] = prms
     print("\n# worst SINGLE-SAMPLE ratio e_hip / e_f32 (one sample = one direction of one seed's chains) over all steps, "
-          "counted only where e_hip exceeds the absolute bar the tests apply first (1e-5 max / 3.3e-6 rms; 2e-5 / 6.7e-6 "
-          "for p): 0.00 = never above the bar.  This is what assert_fp32_equivalent has to allow:")
+          "counted only where e_hip exceeds the absolute bar the tests apply first (1e-5 max / 5e-6 for the 99.9 % quantile "
+          "/ 3.3e-6 rms; 2e-5 / 6.7e-6 for p): 0.00 = never above the bar.  This is what assert_fp32_equivalent has to allow:")
     for k in sorted(worst):
         print(f"#   {k[0]:>6} {k[1]:>8} {k[2]:>6}: {worst[k]:.2f}")
 
