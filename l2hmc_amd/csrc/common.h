@@ -60,6 +60,15 @@ class DeviceOnce {
   }
 };
 
+// ---- XCD-aware tile id: blocks b, b+8, ... share an XCD, give each XCD a
+// contiguous run of logical tiles (bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
 // Optional per-kernel-class timing with HIP events on the launch stream
 // (l2hmc_profile_begin/_end; used by bench.py's roofline pass, off otherwise).
 enum ProfClass { kProfNone = 0, kProfGemmL1 = 1, kProfGemmL2 = 2, kProfHeads = 3, kProfU1 = 4, kProfFused = 5 };

@@ -32,15 +32,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BK = 32;            // k-tile granularity every width must be a multiple of
 constexpr int kGemmThreads = 256;  // 4 waves
 
-// ---- XCD-aware tile id: blocks b, b+8, ... share an XCD, give each XCD a
-// contiguous run of logical tiles (bijective for any grid size).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + slot;
-}
-
 // =====================================================================
 // L1 / L2:  out = relu(A . Wt^T + bias [+ t-term])
 // =====================================================================
