@@ -277,6 +277,95 @@ __global__ __launch_bounds__(256) void vnet_in_bwd_kernel(const float* __restric
   }
 }
 
+// column sums of a taped [calls * rows][n] array (bias gradients), optionally also weighted by the
+// (cos, sin) time input of each (call, row) -- the t_layer kernel's gradient (generic_net.py:131).
+// HBM-bound: every thread streams 16-byte pieces of consecutive rows; a workgroup covers up to 1024
+// columns (blockIdx.x) of one row chunk (blockIdx.y).  part: [S][3][n] (plain, cos-, sin-weighted).
+// One block = column group bx of row chunk by; sm: [nsteps][2] (cos, sin) + 256 * 12 floats of reduction scratch.
+constexpr int kColsumMaxS = 512;
+struct ColsumArgs {
+  const float* src; int64_t Rt; int n;
+  int64_t rows; int nsteps; const int* dir; int timed;
+  int64_t chunk;        // rows per block
+  float* part;          // [S][3][n]
+  int ncg, S;           // column groups (of 1024), row chunks; ncg * S blocks in all (0: no column sums)
+};
+__device__ __forceinline__ void colsum_block(const ColsumArgs& c, int bx, int by, float* sm) {
+  const float* __restrict__ src = c.src;
+  const int* __restrict__ dir = c.dir;
+  const int64_t Rt = c.Rt, rows = c.rows, chunk = c.chunk;
+  const int n = c.n, nsteps = c.nsteps, timed = c.timed;
+  float* __restrict__ part = c.part;
+  float* tab = sm;
+  float* red = sm + 2 * nsteps;
+  if (timed) {
+    for (int i = threadIdx.x; i < nsteps; i += blockDim.x) {
+      const float ang = (float)(2.0 * M_PI) * (float)i / (float)nsteps;
+      tab[2 * i] = cosf(ang);
+      tab[2 * i + 1] = sinf(ang);
+    }
+  }
+  __syncthreads();
+  const int c0 = bx * 1024;
+  const int nc4 = (n - c0 < 1024 ? n - c0 : 1024) / 4;   // 16-byte pieces per row in this column group
+  const int rpp = 256 / nc4 > 0 ? 256 / nc4 : 1;          // rows per pass
+  const int rl = threadIdx.x / nc4, cl = threadIdx.x - rl * nc4;
+  const bool active = rl < rpp;
+  const int64_t rb = (int64_t)by * chunk;
+  const int64_t re = rb + chunk < Rt ? rb + chunk : Rt;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+  if (active) {
+    // (call, row) of the taped row, advanced incrementally: one 64-bit division per thread instead of one per row
+    int64_t call = timed ? (rb + rl) / rows : 0, row = timed ? (rb + rl) - call * rows : 0;
+#pragma unroll 4
+    for (int64_t rr = rb + rl; rr < re; rr += rpp) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + rr * n + c0 + cl * 4);
+      s0 += v;
+      if (timed) {
+        const int step = (int)(call >> 1);
+        const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
+        s1 += tab[2 * i] * v;
+        s2 += tab[2 * i + 1] * v;
+        row += rpp;
+        while (row >= rows) {
+          row -= rows;
+          ++call;
+        }
+      }
+    }
+    float* o = red + (size_t)(rl * nc4 + cl) * 12;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = s0[e];
+      o[4 + e] = s1[e];
+      o[8 + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nc4) {
+    float* o = part + (size_t)by * 3 * n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < rpp; ++q) {
+        const float* r = red + (size_t)(q * nc4 + threadIdx.x) * 12;
+        t0 += r[e];
+        t1 += r[4 + e];
+        t2 += r[8 + e];
+      }
+      const int col = c0 + threadIdx.x * 4 + e;
+      o[col] = t0;
+      o[n + col] = t1;
+      o[2 * n + col] = t2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs c) {
+  extern __shared__ float sm[];
+  colsum_block(c, blockIdx.x, blockIdx.y, sm);
+}
+
 // =====================================================================
 // weight gradients: C[m][n] = sum_r P[r][m] * Q[r][n]   ("TN", contraction over rows)
 // 128 x 128 tile per workgroup, 16 rows per stage, fp32 32x32x2 MFMAs.  Tiles are staged exactly as
@@ -291,6 +380,11 @@ struct GemmTnArgs {
   int64_t chunk;        // rows per split (multiple of 16)
   float* part;          // [splits][M][N]
   int mt, nt;
+  // The bias gradient that belongs to this weight gradient (column sums of P) rides along as cs.ncg * cs.S extra
+  // workgroups behind the product's: HBM-bound blocks that share the CUs with the matrix-pipe-bound ones (a third
+  // workgroup per CU fits beside the product's two), so the sums cost no time of their own.
+  ColsumArgs cs;
+  int nprod;            // workgroups of the product proper (tiles * splits)
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
@@ -299,6 +393,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, r = lane & 31;
   const int tiles = p.mt * p.nt;
+  if (p.cs.ncg) {                                        // uniform per workgroup
+    if ((int)blockIdx.x >= p.nprod) {
+      const int b = blockIdx.x - p.nprod;
+      colsum_block(p.cs, b % p.cs.ncg, b / p.cs.ncg, lds);
+      return;
+    }
+  }
   // (an XCD-aware order -- all tiles of one row range on one XCD -- was measured: no change, the Infinity Cache
   // already serves the cross-XCD re-reads)
   const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
@@ -353,15 +454,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
       if (more) load_stage(rr + BKR);
       const float* ps = lds + cur * 2 * BKR * LDT + wm * 64 + r;
       const float* qs = lds + cur * 2 * BKR * LDT + BKR * LDT + wn * 64 + r;
+      // All 32 operands of the stage are fetched before its first product (counted lgkmcnt waits in between) rather
+      // than four at a time with a full wait per refill.  Measured: no change (5.78 -> 5.76 ms per training step) --
+      // the loop is not latency-bound.  tools/tn_loop_bench.hip takes it apart: MFMAs alone 143 TFLOP/s, + these LDS
+      // reads 126, + barrier 120, + stage stores and global loads 113 (this kernel: 113-115): every register a
+      // load writes costs the matrix pipe about four cycles, at any occupancy (cache-hot loads: no change either).
+      float av[BKR / 2][2], bv[BKR / 2][2];
 #pragma unroll
       for (int kk = 0; kk < BKR / 2; ++kk) {
         const int k = 2 * kk + half;
-        const float a0 = ps[k * LDT], a1 = ps[k * LDT + 32];
-        const float b0 = qs[k * LDT], b1 = qs[k * LDT + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        av[kk][0] = ps[k * LDT]; av[kk][1] = ps[k * LDT + 32];
+        bv[kk][0] = qs[k * LDT]; bv[kk][1] = qs[k * LDT + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < BKR / 2; ++kk) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][0], bv[kk][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][0], bv[kk][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][1], bv[kk][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][1], bv[kk][1], acc[1][1], 0, 0, 0);
       }
       if (more) store_stage(cur ^ 1);
       __syncthreads();
@@ -398,78 +509,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   if (sl == 0 && i < count) out[i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
-// column sums of a taped [calls * rows][n] array (bias gradients), optionally also weighted by the
-// (cos, sin) time input of each (call, row) -- the t_layer kernel's gradient (generic_net.py:131).
-// HBM-bound: every thread streams 16-byte pieces of consecutive rows; a workgroup covers up to 1024
-// columns (blockIdx.x) of one row chunk (blockIdx.y).  part: [S][3][n] (plain, cos-, sin-weighted).
-constexpr int kColsumMaxS = 512;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t Rt, int n,
-                                                     int64_t rows, int nsteps, const int* __restrict__ dir,
-                                                     int timed, int64_t chunk, float* __restrict__ part) {
-  extern __shared__ float sm[];    // [nsteps][2] (cos, sin), then the cross-row reduction scratch
-  float* tab = sm;
-  float* red = sm + 2 * nsteps;
-  if (timed) {
-    for (int i = threadIdx.x; i < nsteps; i += blockDim.x) {
-      const float ang = (float)(2.0 * M_PI) * (float)i / (float)nsteps;
-      tab[2 * i] = cosf(ang);
-      tab[2 * i + 1] = sinf(ang);
-    }
+// The same sum for partials laid out [S][3][n] (colsum_block): plane blockIdx.y goes to its own destination.
+struct PlaneOuts { float* o[3]; };
+__global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restrict__ part, int S, int n,
+                                                            PlaneOuts outs) {
+  __shared__ float red[4][64];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const float* src = part + (size_t)blockIdx.y * n;
+  float t = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int s = sl; s < S; s += 4) t += src[(size_t)s * 3 * n + i];
   }
+  red[sl][il] = t;
   __syncthreads();
-  const int c0 = blockIdx.x * 1024;
-  const int nc4 = (n - c0 < 1024 ? n - c0 : 1024) / 4;   // 16-byte pieces per row in this column group
-  const int rpp = 256 / nc4 > 0 ? 256 / nc4 : 1;          // rows per pass
-  const int rl = threadIdx.x / nc4, cl = threadIdx.x - rl * nc4;
-  const bool active = rl < rpp;
-  const int64_t rb = (int64_t)blockIdx.y * chunk;
-  const int64_t re = rb + chunk < Rt ? rb + chunk : Rt;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
-  if (active) {
-    // (call, row) of the taped row, advanced incrementally: one 64-bit division per thread instead of one per row
-    int64_t call = timed ? (rb + rl) / rows : 0, row = timed ? (rb + rl) - call * rows : 0;
-#pragma unroll 4
-    for (int64_t rr = rb + rl; rr < re; rr += rpp) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + rr * n + c0 + cl * 4);
-      s0 += v;
-      if (timed) {
-        const int step = (int)(call >> 1);
-        const int i = (dir && dir[row]) ? nsteps - 1 - step : step;
-        s1 += tab[2 * i] * v;
-        s2 += tab[2 * i + 1] * v;
-        row += rpp;
-        while (row >= rows) {
-          row -= rows;
-          ++call;
-        }
-      }
-    }
-    float* o = red + (size_t)(rl * nc4 + cl) * 12;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o[e] = s0[e];
-      o[4 + e] = s1[e];
-      o[8 + e] = s2[e];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < nc4) {
-    float* o = part + (size_t)blockIdx.y * 3 * n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-      for (int q = 0; q < rpp; ++q) {
-        const float* r = red + (size_t)(q * nc4 + threadIdx.x) * 12;
-        t0 += r[e];
-        t1 += r[4 + e];
-        t2 += r[8 + e];
-      }
-      const int col = c0 + threadIdx.x * 4 + e;
-      o[col] = t0;
-      o[n + col] = t1;
-      o[2 * n + col] = t2;
-    }
-  }
+  if (sl == 0 && i < n) outs.o[blockIdx.y][i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
 // out[c][r] = in[r][c]
@@ -706,13 +761,18 @@ struct NetTape {
 struct TrainWs {
   NetTape x, v;
   float *mask_inv, *ld, *act0, *kin0, *act1, *kin1, *g, *dg, *din, *dfeat, *part, *eps_part;
+  float* zero_base; size_t zero_bytes;                // dcs_part / dcq_part of both nets + eps_part
   size_t bytes;
 };
 
 static inline int64_t imax64(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
 static int64_t upd_blocks(int64_t rows) { return ceil_div(rows, kUpdRows); }
+// S row chunks of a column-sum pass over Rt taped rows
+static int colsum_chunks(int64_t Rt) { return (int)hmin(kColsumMaxS, imax64(1, Rt / 128)); }
+
 static int tn_splits(int mt, int nt, int64_t R) {
+  // two workgroups per CU; 768 and 1024 measured the same, 256 is 4 % slower (profiles/r02_tn_loop_bench.txt)
   int s = (int)imax64(1, 512 / ((int64_t)mt * nt));
   const int64_t maxs = imax64(1, ceil_div(R, 256));   // at least 256 rows per split
   return (int)hmin(s, maxs);
@@ -749,8 +809,6 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     t.d1 = take(cr * H);
     t.d2 = take(cr * H);
     t.dout = take(cr * 3 * D);
-    t.dcs_part = take((size_t)upd_blocks(rows) * D);
-    t.dcq_part = take((size_t)upd_blocks(rows) * D);
     t.feat = conv ? take(cr * Kin) : nullptr;
     t.conv_part = conv ? take((size_t)ceil_div(rows, conv3d_cpw(p->T, p->X, fronts[k]->F)) * 2 *
                               conv3d_bwd_part_floats(fronts[k]->F))
@@ -764,7 +822,7 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
     const int64_t R = (int64_t)cr;
     auto need = [&](int M, int N) {
       const int mt = (int)ceil_div(M, 128), nt = (int)ceil_div(N, 128);
-      return (size_t)tn_splits(mt, nt, R) * M * N;
+      return (size_t)tn_splits(mt, nt, R) * M * N + (size_t)colsum_chunks(R) * 3 * M;   // product + column sums
     };
     part_max = smax(part_max, smax(need(H, Kin), smax(need(H, H), need(3 * D, H))));
     if (conv) part_max = smax(part_max, 2 * conv3d_bwd_part_floats(fronts[k]->F));
@@ -778,7 +836,15 @@ static TrainWs carve_train_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   w.din = take((size_t)rows * 2 * D);
   w.dfeat = conv ? take((size_t)rows * kin_max) : nullptr;
   w.part = take(part_max);
+  // the += accumulators of the reverse pass, contiguous: one memset clears them all
+  const size_t zero_off = off;
+  w.zero_base = take(0);
+  for (int k = 0; k < 2; ++k) {
+    tapes[k]->dcs_part = take((size_t)upd_blocks(rows) * D);
+    tapes[k]->dcq_part = take((size_t)upd_blocks(rows) * D);
+  }
   w.eps_part = take(upd_blocks(rows));
+  w.zero_bytes = off - zero_off;
   w.bytes = off;
   return w;
 }
@@ -913,44 +979,63 @@ static int call_backward_data(const l2hmc_gauge_plan* p, const l2hmc_dense_net* 
   return launch_conv3d_front_bwd(b, s);
 }
 
+static ColsumArgs colsum_args(const float* src, int64_t Rt, int n, int64_t rows, int nsteps, const int* dir,
+                              int timed, float* part) {
+  ColsumArgs c{};
+  c.src = src; c.Rt = Rt; c.n = n; c.rows = rows; c.nsteps = nsteps; c.dir = dir; c.timed = timed;
+  c.S = colsum_chunks(Rt);
+  c.chunk = ceil_div(Rt, c.S);
+  c.ncg = (int)ceil_div(n, 1024);
+  c.part = part;
+  return c;
+}
+
+// partials [S][3][n] -> the one or three planes, each summed in a fixed order straight into its gradient slot
+static int colsum_finish(const ColsumArgs& c, float* out_plain, float* out_cos, float* out_sin, hipStream_t s) {
+  const PlaneOuts outs{{out_plain, out_cos, out_sin}};
+  hipLaunchKernelGGL(reduce_planes_kernel, dim3((unsigned)ceil_div(c.n, 64), c.timed ? 3 : 1), dim3(256), 0, s,
+                     c.part, c.S, c.n, outs);
+  L2HMC_CHECK_LAUNCH("reduce_planes");
+  return L2HMC_OK;
+}
+
+// out = P^T . Q; with b_plain != NULL also the column sums of P -- the bias gradient of the same layer (b_cos /
+// b_sin: weighted by each taped row's time input, the t_layer kernel's gradient) -- as extra workgroups of the
+// same launch (see GemmTnArgs::cs)
 static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, float* out, const TrainWs& w,
-                   hipStream_t s) {
+                   hipStream_t s, float* b_plain = nullptr, float* b_cos = nullptr, float* b_sin = nullptr,
+                   int64_t rows = 0, int nsteps = 0, const int* dir = nullptr) {
   GemmTnArgs a{};
   a.P = P; a.ldp = M; a.M = M; a.Q = Q; a.ldq = N; a.N = N; a.R = R;
   a.mt = (int)ceil_div(M, 128); a.nt = (int)ceil_div(N, 128);
   const int splits = tn_splits(a.mt, a.nt, R);
   a.chunk = (int64_t)align_up((size_t)ceil_div(R, splits), 16);
   a.part = w.part;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.mt * a.nt * splits), dim3(256), 0, s, a);
+  a.nprod = a.mt * a.nt * splits;
+  const bool timed = b_cos != nullptr;
+  if (b_plain) {
+    L2HMC_REQUIRE(M % 4 == 0, "gemm_tn: column sums need a width (%d) that is a multiple of 4", M);
+    L2HMC_REQUIRE(!timed || (b_sin && rows > 0 && nsteps > 0 && 2 * nsteps + 256 * 12 <= 2 * 2 * 16 * 160),
+                  "gemm_tn: bad column-sum arguments");
+    a.cs = colsum_args(P, R, M, rows, nsteps, dir, timed ? 1 : 0, w.part + (size_t)splits * M * N);
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nprod + a.cs.ncg * a.cs.S), dim3(256), 0, s, a);
   L2HMC_CHECK_LAUNCH("gemm_tn");
   const int64_t count = (int64_t)M * N;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(count, 64)), dim3(256), 0, s, w.part, splits,
                      count, out);
   L2HMC_CHECK_LAUNCH("reduce_partials");
-  return L2HMC_OK;
+  return b_plain ? colsum_finish(a.cs, b_plain, b_cos, b_sin, s) : L2HMC_OK;
 }
 
+// stand-alone column sums (deltas whose weight gradient is not a TN product of this file)
 static int colsum(const float* src, int64_t Rt, int n, int64_t rows, int nsteps, const int* dir, int timed,
                   float* out_plain, float* out_cos, float* out_sin, const TrainWs& w, hipStream_t s) {
   L2HMC_REQUIRE(n % 4 == 0, "colsum: width %d must be a multiple of 4", n);
-  const int S = (int)hmin(kColsumMaxS, imax64(1, Rt / 128));
-  const int64_t chunk = ceil_div(Rt, S);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 1024), S), dim3(256),
-                     sizeof(float) * (2 * nsteps + 256 * 12), s, src, Rt, n, rows, nsteps, dir, timed, chunk, w.part);
+  const ColsumArgs c = colsum_args(src, Rt, n, rows, nsteps, dir, timed, w.part);
+  hipLaunchKernelGGL(colsum_kernel, dim3(c.ncg, c.S), dim3(256), sizeof(float) * (2 * nsteps + 256 * 12), s, c);
   L2HMC_CHECK_LAUNCH("colsum");
-  // partials are [S][3][n]: reduce each plane with stride 3n
-  // (reduce_partials_kernel sums part[s * count + i]; use count = 3n and a scratch of 3n, then split)
-  float* tmp = w.part + (size_t)S * 3 * n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(3 * n, 64)), dim3(256), 0, s, w.part, S,
-                     (int64_t)3 * n, tmp);
-  L2HMC_CHECK_LAUNCH("reduce_partials");
-  if (hipMemcpyAsync(out_plain, tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      (timed && (hipMemcpyAsync(out_cos, tmp + n, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                 hipMemcpyAsync(out_sin, tmp + 2 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess))) {
-    set_error("hipMemcpyAsync failed in colsum");
-    return L2HMC_ERR_HIP;
-  }
-  return L2HMC_OK;
+  return colsum_finish(c, out_plain, out_cos, out_sin, s);
 }
 
 }  // namespace l2hmc
@@ -1047,11 +1132,7 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
   hipStream_t s = (hipStream_t)stream;
   const int D = 2 * plan->T * plan->X, N = plan->num_steps, C = 2 * N;
   const int64_t nblk = upd_blocks(rows);
-  if (hipMemsetAsync(w.x.dcs_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
-      hipMemsetAsync(w.x.dcq_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
-      hipMemsetAsync(w.v.dcs_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
-      hipMemsetAsync(w.v.dcq_part, 0, sizeof(float) * nblk * D, s) != hipSuccess ||
-      hipMemsetAsync(w.eps_part, 0, sizeof(float) * nblk, s) != hipSuccess) {
+  if (hipMemsetAsync(w.zero_base, 0, w.zero_bytes, s) != hipSuccess) {
     set_error("train_backward: memset failed");
     return L2HMC_ERR_HIP;
   }
@@ -1160,14 +1241,24 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
     // three gradient buckets per network, each finished (weights, then the biases that go with them) before the
     // next product starts, so a caller can put bucket b on the wire while bucket b + 1 is being computed:
     //   3k + 0: [w1_t | wt | b1]      3k + 1: [wh_t | bh]      3k + 2: [whd_t | bhd | coeff_s | coeff_q]
-    if (int e = gemm_tn(t.d1, H, conv ? t.feat : t.in, Kin, Rt, g->w1_t, w, s)) return e;
-    if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
-    if (on_bucket) on_bucket(user, 3 * k + 0);
-    if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
-    if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
-    if (on_bucket) on_bucket(user, 3 * k + 1);
-    if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
-    if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
+    if (2 * N + 256 * 12 <= 2 * 2 * 16 * 160) {
+      // the bias gradients (column sums of the deltas) ride in the launches of the weight-gradient products
+      if (int e = gemm_tn(t.d1, H, conv ? t.feat : t.in, Kin, Rt, g->w1_t, w, s, g->b1, g->wt, g->wt + H, rows, N, dir))
+        return e;
+      if (on_bucket) on_bucket(user, 3 * k + 0);
+      if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s, g->bh)) return e;
+      if (on_bucket) on_bucket(user, 3 * k + 1);
+      if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s, g->bhd)) return e;
+    } else {
+      if (int e = gemm_tn(t.d1, H, conv ? t.feat : t.in, Kin, Rt, g->w1_t, w, s)) return e;
+      if (int e = colsum(t.d1, Rt, H, rows, N, dir, 1, g->b1, g->wt, g->wt + H, w, s)) return e;
+      if (on_bucket) on_bucket(user, 3 * k + 0);
+      if (int e = gemm_tn(t.d2, H, t.h1, H, Rt, g->wh_t, w, s)) return e;
+      if (int e = colsum(t.d2, Rt, H, rows, N, dir, 0, g->bh, nullptr, nullptr, w, s)) return e;
+      if (on_bucket) on_bucket(user, 3 * k + 1);
+      if (int e = gemm_tn(t.dout, 3 * D, t.h2, H, Rt, g->whd_t, w, s)) return e;
+      if (int e = colsum(t.dout, Rt, 3 * D, rows, N, dir, 0, g->bhd, nullptr, nullptr, w, s)) return e;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcs_part,
                        (int)ncoef, (int64_t)D, g->coeff_s);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(D, 64)), dim3(256), 0, s, t.dcq_part,
