@@ -93,6 +93,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sums over lanes 0..31 and 32..63 separately: valid in lanes 31 and 63 of the returned value
+__device__ __forceinline__ float wave_half_sums(float v) {
+  v += dpp_take<0xB1, 0xf>(v);
+  v += dpp_take<0x4E, 0xf>(v);
+  v += dpp_take<0x141, 0xf>(v);
+  v += dpp_take<0x140, 0xf>(v);
+  v += dpp_take<0x142, 0xa>(v);       // row_bcast:15: lanes of row 1 hold rows 0 + 1, lanes of row 3 rows 2 + 3
+  return v;
+}
+
 // Philox4x32-10 (Salmon et al., SC'11) and the word -> float maps shared by every generator in the library
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -132,90 +132,94 @@ __global__ __launch_bounds__(kLatThreads) void u1_action_force_kernel(
   }
 }
 
-// Fast path for lattices whose site count divides the workgroup (8x8: 4 chains, 16x16: 1 chain per pass):
-// one site per thread, every index and neighbour offset is loop-invariant, workgroups are persistent
-// (grid-stride over chain groups, the next group's links are in flight while the current one is computed),
-// and the scalar observables are compiled out when only the force is wanted (the integrator's case).
-template <bool SCALARS>
-__global__ __launch_bounds__(kLatThreads) void u1_fast_kernel(
+// Fast path for even X with 64 ... 1024 sites per chain: every thread owns the two sites (i, j), (i, j + 1) of a row
+// -- ONE 16-byte load and ONE 16-byte store per thread -- and every workgroup exactly one group of chains (one-shot
+// grid, no persistence).  tools/stream_shape_bench.hip measured the shapes on MI355X for this read-once /
+// write-once stream with an LDS neighbour exchange and two barriers: 8 bytes per thread 5.4-5.5 TB/s (persistent
+// or one-shot; the previous form of this kernel), 16 bytes per thread one-shot 6.4 TB/s -- the same as an
+// element-wise kernel without any exchange (profiles/r02_stream_shape_bench.txt).
+// Thread l of a chain: row i = l / (X/2), column pair jh = l % (X/2).
+//   P[i,j] = x0[i,j] - x1[i,j] - x0[i,j+1] + x1[i+1,j];  dS/dx0[i,j] = beta (sin P[i,j] - sin P[i,j-1]),
+//   dS/dx1[i,j] = beta (-sin P[i,j] + sin P[i-1,j])   (lattice.py:285-362, gauge_dynamics.py:592-609)
+template <bool SCALARS, int THREADS>
+__global__ __launch_bounds__(THREADS) void u1_pair_kernel(
     const float* __restrict__ x, int64_t rows, int T, int X, float beta, int cpw,
     float* __restrict__ action, float* __restrict__ force, float* __restrict__ avg_plaq,
     float* __restrict__ top_charge) {
-  __shared__ float2 xs[2][kLatThreads];
-  __shared__ float sp[2][kLatThreads];
-  __shared__ float red[kLatThreads / kWave][3];
-  const int sites = T * X;
+  __shared__ float2 x1s[THREADS];            // (x1[i,j], x1[i,j+1])
+  __shared__ float x0s[THREADS];             // x0[i,j]
+  __shared__ float2 sps[THREADS];            // (sin P[i,j], sin P[i,j+1])
+  __shared__ float red[THREADS / kWave][2];
+  const int sites = T * X, lpc = sites >> 1, X2 = X >> 1;
   const int tid = threadIdx.x;
-  const int c = tid / sites, site = tid - c * sites;
-  const int i = site / X, j = site - i * X;
-  const int base = c * sites;
-  const int n_jp = base + i * X + ((j + 1 == X) ? 0 : j + 1);
-  const int n_ip = base + ((i + 1 == T) ? 0 : i + 1) * X + j;
-  const int n_jm = base + i * X + ((j == 0) ? X - 1 : j - 1);
-  const int n_im = base + ((i == 0) ? T - 1 : i - 1) * X + j;
-  const int64_t ngroups = (rows + cpw - 1) / cpw;
-  const float2* x2 = reinterpret_cast<const float2*>(x);
-  float2* f2 = reinterpret_cast<float2*>(force);
+  // lpc is a power of two on this path; X / 2 usually is (shift instead of the ~30-instruction integer division)
+  const int lsh = 31 - __builtin_clz(lpc);
+  const int c = tid >> lsh, l = tid & (lpc - 1);
+  const int i = (X2 & (X2 - 1)) == 0 ? l >> (31 - __builtin_clz(X2)) : l / X2, jh = l - i * X2;
+  const int base = c * lpc;
+  const int n_right = base + i * X2 + ((jh + 1 == X2) ? 0 : jh + 1);
+  const int n_left = base + i * X2 + ((jh == 0) ? X2 - 1 : jh - 1);
+  const int n_up = base + ((i + 1 == T) ? 0 : i + 1) * X2 + jh;
+  const int n_down = base + ((i == 0) ? T - 1 : i - 1) * X2 + jh;
   const float inv_two_pi = 0.15915494309189533577f;
-
-  int64_t grp = blockIdx.x;
-  float2 nxt = make_float2(0.f, 0.f);
-  if (grp < ngroups) {
-    const int64_t row = grp * cpw + c;
-    if (row < rows) nxt = x2[row * sites + site];
-  }
-  int buf = 0;
-  for (; grp < ngroups; grp += gridDim.x, buf ^= 1) {
-    const int64_t row = grp * cpw + c;
-    const float2 xv = nxt;
-    xs[buf][tid] = xv;
-    const int64_t g2 = grp + gridDim.x;           // prefetch the next group's links
-    nxt = make_float2(0.f, 0.f);
-    if (g2 < ngroups) {
-      const int64_t r2 = g2 * cpw + c;
-      if (r2 < rows) nxt = x2[r2 * sites + site];
-    }
-    __syncthreads();
-    const float P = xv.x - xv.y - xs[buf][n_jp].x + xs[buf][n_ip].y;
-    float sn, cs = 0.f;
-    fast_sincos(P, &sn, &cs);
-    sp[buf][tid] = sn;
-    if (SCALARS) {
-      // S = sum (1 - cos P) = sites - sum cos P: one reduction serves action and plaquette (the two differ by
-      // rounding of order 1e-7 relative; the kernel is VALU-bound once it produces observables)
-      const float q = wave_sum(cs);
-      const float ch = wave_sum(P - kTwoPi * floorf((P + kPi) * inv_two_pi));
-      if (sites == kWave) {
-        if ((tid & 63) == 0 && row < rows) {
+  const int64_t row = (int64_t)blockIdx.x * cpw + c;
+  const bool live = row < rows;
+  const float4 a = reinterpret_cast<const float4*>(x)[(live ? row : rows - 1) * lpc + l];
+  x1s[tid] = make_float2(a.y, a.w);
+  x0s[tid] = a.x;
+  __syncthreads();
+  const float2 up = x1s[n_up];
+  const float PA = a.x - a.y - a.z + up.x;
+  const float PB = a.z - a.w - x0s[n_right] + up.y;
+  float sA, cA = 0.f, sB, cB = 0.f;
+  fast_sincos(PA, &sA, &cA);
+  fast_sincos(PB, &sB, &cB);
+  sps[tid] = make_float2(sA, sB);
+  if (SCALARS) {
+    // S = sum (1 - cos P) = sites - sum cos P: one reduction serves action and plaquette
+    const float qv = cA + cB;
+    const float cv = (PA - kTwoPi * floorf((PA + kPi) * inv_two_pi)) + (PB - kTwoPi * floorf((PB + kPi) * inv_two_pi));
+    if (lpc == 32) {                         // two chains per wave
+      const float q = wave_half_sums(qv), ch = wave_half_sums(cv);
+      if ((tid & 31) == 31 && live) {
+        if (action) action[row] = (float)sites - q;
+        if (avg_plaq) avg_plaq[row] = q / (float)sites;
+        if (top_charge) top_charge[row] = ch * inv_two_pi;
+      }
+    } else {
+      const float q = wave_sum(qv), ch = wave_sum(cv);
+      if (lpc == kWave) {
+        if ((tid & 63) == 0 && live) {
           if (action) action[row] = (float)sites - q;
           if (avg_plaq) avg_plaq[row] = q / (float)sites;
           if (top_charge) top_charge[row] = ch * inv_two_pi;
         }
       } else if ((tid & 63) == 0) {
-        red[tid >> 6][1] = q;
-        red[tid >> 6][2] = ch;
+        red[tid >> 6][0] = q;
+        red[tid >> 6][1] = ch;
       }
     }
-    __syncthreads();
-    if (SCALARS && sites != kWave && site == 0 && row < rows) {
-      const int w0 = base / kWave, nw = sites / kWave;
-      float q = 0.f, ch = 0.f;
-      for (int w = 0; w < nw; ++w) {
-        q += red[w0 + w][1];
-        ch += red[w0 + w][2];
-      }
-      if (action) action[row] = (float)sites - q;
-      if (avg_plaq) avg_plaq[row] = q / (float)sites;
-      if (top_charge) top_charge[row] = ch * inv_two_pi;
+  }
+  __syncthreads();
+  if (SCALARS && lpc > kWave && l == 0 && live) {
+    const int w0 = base / kWave, nw = lpc / kWave;
+    float q = 0.f, ch = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      q += red[w0 + w][0];
+      ch += red[w0 + w][1];
     }
-    if (force && row < rows) {
-      float2 g;
-      g.x = beta * (sn - sp[buf][n_jm]);
-      g.y = beta * (-sn + sp[buf][n_im]);
-      f2[row * sites + site] = g;
-    }
-    // xs/sp are double-buffered: the next iteration writes the other buffer, and its first barrier orders
-    // this iteration's reads of `red` against the next writes
+    if (action) action[row] = (float)sites - q;
+    if (avg_plaq) avg_plaq[row] = q / (float)sites;
+    if (top_charge) top_charge[row] = ch * inv_two_pi;
+  }
+  if (force && live) {
+    const float2 dn = sps[n_down];
+    float4 g;
+    g.x = beta * (sA - sps[n_left].y);
+    g.y = beta * (-sA + dn.x);
+    g.z = beta * (sB - sA);
+    g.w = beta * (-sB + dn.y);
+    reinterpret_cast<float4*>(force)[row * lpc + l] = g;
   }
 }
 
@@ -254,18 +258,26 @@ __global__ __launch_bounds__(256) void kinetic_kernel(const float* __restrict__ 
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream) {
   const int sites = T * X;
-  if (sites % kWave == 0 && kLatThreads % sites == 0) {
-    const int cpwf = kLatThreads / sites;
+  // pair kernel: even X, sites / 2 lanes per chain dividing the workgroup (256 threads; 512 for 1024 sites), rows
+  // 16-byte aligned (sites * 8 bytes per row is, the bases must be)
+  const int lpc = sites / 2;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(force)) & 15) == 0;
+  if (X % 2 == 0 && aligned && (lpc == 32 || lpc == 64 || lpc == 128 || lpc == 256 || lpc == 512)) {
+    const int threads = lpc == 512 ? 512 : 256;      // (512 threads for the smaller lattices too: measured 0-7 % slower)
+    const int cpwf = threads / lpc;
     const int64_t ngroups = ceil_div(rows, cpwf);
-    const unsigned gridf = (unsigned)hmin(ngroups, 256 * 8);
+    L2HMC_REQUIRE(ngroups < (1ll << 31), "u1_action_force: too many rows");
     const bool scalars = action || avg_plaq || top_charge;
     prof_before(kProfU1, stream);
-    if (scalars)
-      hipLaunchKernelGGL(u1_fast_kernel<true>, dim3(gridf), dim3(kLatThreads), 0, stream, x, rows, T, X, beta, cpwf,
-                         action, force, avg_plaq, top_charge);
-    else
-      hipLaunchKernelGGL(u1_fast_kernel<false>, dim3(gridf), dim3(kLatThreads), 0, stream, x, rows, T, X, beta,
-                         cpwf, action, force, avg_plaq, top_charge);
+#define L2HMC_U1_PAIR(SC, TH)                                                                                   \
+  hipLaunchKernelGGL((u1_pair_kernel<SC, TH>), dim3((unsigned)ngroups), dim3(TH), 0, stream, x, rows, T, X, beta, \
+                     cpwf, action, force, avg_plaq, top_charge)
+    if (scalars) {
+      if (threads == 512) L2HMC_U1_PAIR(true, 512); else L2HMC_U1_PAIR(true, 256);
+    } else {
+      if (threads == 512) L2HMC_U1_PAIR(false, 512); else L2HMC_U1_PAIR(false, 256);
+    }
+#undef L2HMC_U1_PAIR
     prof_after(kProfU1, stream);
     L2HMC_CHECK_LAUNCH("u1_action_force");
     return L2HMC_OK;

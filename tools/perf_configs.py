@@ -91,6 +91,13 @@ def u1_roofline():
             nbytes = rows * (8 * D + extra)
             print(f"u1_action_force {L}x{L} rows={rows} {what:38s}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.0f} GB/s algorithmic "
                   f"({nbytes/dt/8e12:.2f} of 8 TB/s)", flush=True)
+        # the same buffers through a plain device copy and an element-wise op, timed the same way: what this
+        # read-once / write-once pattern reaches on this part without any arithmetic or neighbour exchange
+        for what, fn in (("torch copy_ (same bytes: reference point)", lambda: f.copy_(x)),
+                         ("torch sin(x, out=f) (same bytes: reference point)", lambda: torch.sin(x, out=f))):
+            dt = timeit(fn, warm=3, iters=10)
+            nbytes = rows * 8 * D
+            print(f"   {what:60s}: {dt*1e3:.3f} ms  {nbytes/dt/1e9:.0f} GB/s ({nbytes/dt/8e12:.2f} of 8 TB/s)", flush=True)
         del x, f
 
 
