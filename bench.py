@@ -159,7 +159,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (L2HMC_COLLECTIVES_AT_WORLD1=1: one-GPU rehearsal of the sharded flow -- a one-rank RCCL group is created and
+    #  every collective below is really issued, see l2hmc_amd/dist.py:active)
+    rehearse1 = world == 1 and os.environ.get("L2HMC_COLLECTIVES_AT_WORLD1") == "1"
+    if rehearse1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or rehearse1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -394,7 +401,8 @@ def main():
                 "what": "loss + hand-written reverse pass + gradient all-reduce + Adam, 2048 x-chains and 2048 "
                         "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
                 "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
-                "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss)}
+                "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss),
+                "grad_buckets": int(tr.last_bucket_count) if tr.dist is not None else 0}
             if world == 1 and not args.no_trained_ess:
                 # the secondary metric with TRAINED networks: a short training run (same shape), then ESS/sec of
                 # the sampler with the estimator used above (untrained networks barely move a chain)

@@ -3,7 +3,19 @@ owns a contiguous block of chains and a replica of the weights / masks; the
 only exchange is one fused all-reduce of per-step scalar sums (the reduce_mean
 of gauge_model.py:795 across shards).  `torch.distributed` with backend "nccl"
 is RCCL over xGMI on ROCm; the same code runs on "gloo" for CPU tests."""
+import os
+
 import torch
+
+
+def active(dist):
+    """`dist` if its collectives are to be issued, else None.  A single rank has nothing to exchange and skips
+    them -- unless L2HMC_COLLECTIVES_AT_WORLD1=1 (a rehearsal knob for a one-GPU box: every all-reduce / broadcast /
+    barrier of the sharded path is then really issued through RCCL with world_size 1, where it changes no value)."""
+    if dist is None or not dist.is_initialized():
+        return None
+    floor = 1 if os.environ.get("L2HMC_COLLECTIVES_AT_WORLD1") == "1" else 2
+    return dist if dist.get_world_size() >= floor else None
 
 
 def shard_bounds(num_chains, world_size, rank):
@@ -29,7 +41,7 @@ class StepStats:
 
     def __init__(self, device, dist=None):
         self.device = torch.device(device)
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = active(dist)
         self.total = torch.zeros(3, dtype=torch.float64)
         self._pending = []
         self._count, self._count_n = None, -1

@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .dist import active as _active_dist
 
 
 class DynamicsTrainer:
@@ -21,7 +22,7 @@ class DynamicsTrainer:
         self.scale = float(scale)
         self.lr_init, self.lr_decay_steps, self.lr_decay_rate = float(lr_init), int(lr_decay_steps), float(lr_decay_rate)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = _active_dist(dist)
         self.world = self.dist.get_world_size() if self.dist is not None else 1
         self.global_step, self._adam_t = 0, 0
         dev = dyn._device

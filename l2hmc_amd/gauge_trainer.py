@@ -18,6 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .dist import active as _active_dist
 from .lattice import u1_observables
 
 METRICS = {'l1': 0, 'l2': 1, 'cos': 2, 'cos2': 3, 'cos_diff': 4}
@@ -42,7 +43,7 @@ class GaugeTrainer:
         self.lr_init, self.lr_decay_steps, self.lr_decay_rate = float(lr_init), int(lr_decay_steps), float(lr_decay_rate)
         self.clip_value = None if clip_value is None else float(clip_value)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = _active_dist(dist)
         self.world = self.dist.get_world_size() if self.dist is not None else 1
         self.allreduce_grads = bool(allreduce_grads)
         # bucketed: gradient groups go on the wire as soon as the reverse pass has produced them, on a side stream,
