@@ -1065,6 +1065,64 @@ def test_cfg4_conv3d_at_its_real_trajectory_length(la):
     assert np.abs(got[2] - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())
 
 
+def _full_size_properties(dyn, x, v, beta, rev_tol):
+    """Size-independent properties of a whole trajectory at a BASELINE per-GPU batch (no oracle run at this size):
+    (1) the backward trajectory undoes the forward one and the log-dets cancel (gauge_dynamics.py:537-590),
+    (2) the launch is deterministic, (3) accept probabilities lie in [0, 1], (4) a whole MCMC step returns, chain by
+    chain, either its proposal or its input, wrapped observables are finite."""
+    x1, v1, p1, ld1 = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+    x2, v2, p2, ld2 = dyn.transition_kernel(x1, beta, forward=False, momentum=v1, return_logdet=True)
+    # rev_tol = (rms, max) bounds on the round trip: 2N chaotic steps amplify fp32 rounding, the tail of millions of
+    # elements more than their bulk.  Measured rms / max relative error of v (the worst of x, v, logdet):
+    # cfg 3 (20 steps) 1.8e-5 / 3.6e-4, cfg 4 (30) 7.7e-5 / 1.6e-3, cfg 5 (50) 2.0e-4 / 5.9e-3.
+    rms_tol, max_tol = rev_tol
+    for got, want in ((x2, x), (v2, v), (ld2, -ld1)):
+        d = (got - want).double()
+        scale = max(1.0, float(want.double().pow(2).mean().sqrt()))
+        assert float(d.pow(2).mean().sqrt()) / scale < rms_tol
+        assert H.relerr(np_(got), np_(want)) < max_tol
+    x1b, _, p1b, _ = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+    assert torch.equal(x1, x1b) and torch.equal(p1, p1b)
+    assert torch.isfinite(x1).all() and torch.all((p1 >= 0) & (p1 <= 1)) and torch.all((p2 >= 0) & (p2 <= 1))
+    out = dyn(x, beta)
+    same = (out[3] == x).all(1) | (out[3] == out[0]).all(1)
+    assert bool(same.all())
+    return x1, v1, p1
+
+
+def test_full_size_properties_cfg4(la):
+    """BASELINE.json configs[3] at its per-GPU size: 16x16, ConvNet3D F=16 / H=1024, 1024 chains (8192 over 8
+    GPUs), 15 LF steps, eps 0.2, beta 3.  The first 4 chains are also held against the oracle."""
+    L, N, eps, beta, B = 16, 15, 0.2, 3.0, 1024
+    D = 2 * L * L
+    xp, vp = H.conv_weights(L, L, regime="init")
+    orc = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D')
+    orc32 = H.gauge_oracle(L, L, N, eps, xp, vp, arch='conv3D', dtype=np.float32)
+    dyn = H.gauge_hip(L, L, N, eps, xp, vp, orc.mask, B, arch='conv3D')
+    torch.manual_seed(4)
+    x = torch.rand(B, D, device="cuda") * (2 * np.pi)
+    v = torch.randn(B, D, device="cuda")
+    x1, v1, p1 = _full_size_properties(dyn, x, v, beta, (3e-4, 5e-3))
+    xs, vs = np_(x[:4]), np_(v[:4])
+    want = orc.transition_kernel(xs, beta, vs, forward=True)
+    w32 = orc32.transition_kernel(xs.astype(np.float32), beta, vs.astype(np.float32), forward=True)
+    assert_fp32_equivalent(np_(x1[:4]), want[0], w32[0], "x (first 4 chains)")
+    assert_fp32_equivalent(np_(v1[:4]), want[1], w32[1], "v (first 4 chains)")
+
+
+def test_full_size_properties_cfg5(la, cfg5):
+    """BASELINE.json configs[4] at its per-GPU size: 32x32, GenericNet D=2048 / H=8192, 2048 chains (16384 over 8
+    GPUs), 25 LF steps, eps 0.1, beta 4 -- 4096 rows x 50 network calls of 151 M parameters per launch."""
+    T, X, xp, vp = cfg5
+    N, eps, beta, B, D = 25, 0.1, 4.0, 2048, 2 * T * X
+    masks = H.gauge_oracle(T, X, N, eps, xp, vp).mask
+    dyn = H.gauge_hip(T, X, N, eps, xp, vp, masks, B)
+    torch.manual_seed(5)
+    x = torch.rand(B, D, device="cuda") * (2 * np.pi)
+    v = torch.randn(B, D, device="cuda")
+    _full_size_properties(dyn, x, v, beta, (8e-4, 2e-2))
+
+
 def test_chain_statistics_on_device_histories(la):
     """f4: the estimators behind ESS/sec and tau_int (utils/func_utils.py:45-54,114-120, utils/autocorr.py:23-199)
     fed a DEVICE tensor history -- what a device-resident run keeps in HBM -- against the lag-sum restatements of
