@@ -356,8 +356,14 @@ def main():
         out["config"]["mog_cfg2"] = {
             "workload": "2-D mixture of Gaussians, 4096 chains per GPU, 10 LF steps, MLP H=50 (BASELINE.json configs[1])",
             "ms_per_propose": 1e3 * tmd, "chain_leapfrog_steps_per_s": world * 4096 * 10 / tmd,
-            "bound": "latency (a wave walks 40 dependent network calls for its 16 chains; hidden layer and heads on "
-                     "16x16x4 fp32 MFMAs, DESIGN.md K4)"}
+            # 4 network calls per LF step and direction; MACs per call and chain: two 2 x 50 input layers, the time
+            # layer, 50 x 50 hidden, three 50 x 2 heads
+            "algorithmic_tflops": 2 * 4096 * 40 * 2 * (2 * 2 * 50 + 2 * 50 + 50 * 50 + 3 * 2 * 50) / tmd / 1e12,
+            "frac_of_fp32_mfma_peak": 2 * 4096 * 40 * 2 * (2 * 2 * 50 + 2 * 50 + 50 * 50 + 3 * 2 * 50) / tmd / 1e12
+            / PEAK_F32_MFMA_TFLOPS,
+            "bound": "latency (one launch per propose: Philox draws, both trajectories, mix and MH in the kernel; a "
+                     "wave walks 40 dependent network calls for its 8 chains x 2 directions -- 512 waves on 1024 "
+                     "SIMDs; hidden layer and heads on 16x16x4 fp32 MFMAs with register-resident weights, DESIGN.md K4)"}
     except Exception as e:                        # noqa: BLE001
         out["config"]["mog_cfg2"] = {"error": repr(e)}
 

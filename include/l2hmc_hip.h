@@ -390,6 +390,16 @@ int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const 
                            const int32_t* dir, int64_t rows, float* x_out, float* v_out,
                            float* sumlogdet, float* p_accept, l2hmc_stream_t stream);
 
+/* utils/sampler.py:28-55 `propose` (and :57-59 `tf_accept` when x_out != NULL) in ONE launch for the L2HMC sampler
+ * (plan->hmc == 0).  Chain c's direction bit, forward momentum, backward momentum and Metropolis-Hastings uniform are
+ * the Philox streams (seed, draw0), (seed, draw0 + 1), (seed, draw0 + 2), (seed, draw0 + 3): exactly the elements
+ * l2hmc_fill_uniform(B) / l2hmc_fill_normal(B * x_dim) write with those (seed, offset) pairs, so the call equals
+ * fill x 4 + l2hmc_small_trajectory(2B rows) + l2hmc_mix_accept(strict = 0) bit for bit.  Both trajectories of a
+ * chain run in the same wave.  Outputs (each may be NULL): Lx, Lv [B][x_dim] the proposal selected by the direction
+ * bit (forward iff uniform >= 0.5), px [B] its accept probability, x_out [B][x_dim] = Lx where px - u >= 0 else x. */
+int l2hmc_small_propose(const l2hmc_small_plan* plan, const float* x, int64_t B, uint64_t seed, uint64_t draw0,
+                        float* Lx, float* Lv, float* px, float* x_out, l2hmc_stream_t stream);
+
 /* One training evaluation on the toy targets (mog_model.py:324-363): `rows` = 2B stacked chains (B started at
  * x, B at z ~ N(0,1); sampler.py:28-55 picks a direction per chain, passed in `dir`), each integrated in its
  * direction; per chain v = |x0 - x_N|^2 * p + 1e-4, term = scale / v - v / scale, loss = inv_count * sum of all

@@ -494,6 +494,47 @@ def test_generic_dynamics_and_propose(la, name):
         la.Dynamics(2, lambda x: x.sum(1), trajectory_length=3, eps=0.1, net_factory=la.network)
 
 
+@pytest.mark.parametrize("name,B", [("mog_cfg2", 4096), ("scg_cfg1", 61)])
+def test_one_launch_propose_equals_the_piecewise_path_bit_for_bit(la, name, B):
+    """l2hmc_small_propose (direction bit, both momenta, both trajectories, mix and MH in ONE launch) against the
+    same library streams written out with l2hmc_fill_* and fed to the piecewise path (two-direction trajectory
+    launch + l2hmc_mix_accept): identical bits, ragged batch included (61 chains: partial wave)."""
+    import ctypes as C
+    from l2hmc_amd import _lib
+    g, tgt, dyn = _small(la, name)
+    rng = np.random.default_rng(5)
+    x = torch.as_tensor(rng.standard_normal((B, 2)) * 0.7 + 0.3, dtype=torch.float32, device="cuda")
+    seed, d0 = dyn._seed, 10
+    L = _lib.lib()
+
+    def fill(fn, n, off):
+        out = torch.empty(n, device="cuda")
+        _lib.check(fn(out.data_ptr(), n, seed, off, None))
+        return out
+    bits = (fill(L.l2hmc_fill_uniform, B, d0) >= 0.5).float()
+    vf = fill(L.l2hmc_fill_normal, 2 * B, d0 + 1).reshape(B, 2)
+    vb = fill(L.l2hmc_fill_normal, 2 * B, d0 + 2).reshape(B, 2)
+    u = fill(L.l2hmc_fill_uniform, B, d0 + 3)
+    Lx, Lv, px, outs = la.propose(x, dyn, init_v=vf, do_mh_step=True, init_v_backward=vb, dir_bits=bits, u=u)
+    # the host class with library draws: one launch, the draw counter moves by four (three without the MH step)
+    dyn._draws = d0
+    Lx1, Lv1, px1, outs1 = la.propose(x, dyn, do_mh_step=True)
+    assert dyn._draws == d0 + 4 and Lv1 is None
+    assert torch.equal(Lx1, Lx) and torch.equal(px1, px) and torch.equal(outs1[0], outs[0])
+    assert 0.2 < float(bits.mean()) < 0.8 and not torch.equal(outs[0], Lx) and not torch.equal(outs[0], x)
+    dyn._draws = d0
+    Lx2, _, px2, outs2 = la.propose(x, dyn, do_mh_step=False)
+    assert dyn._draws == d0 + 3 and outs2 == [] and torch.equal(Lx2, Lx) and torch.equal(px2, px)
+    # the C entry also hands out the mixed momentum
+    plan = dyn._plan()
+    Lv3 = torch.empty_like(x)
+    _lib.check(L.l2hmc_small_propose(C.byref(plan), x.data_ptr(), B, seed, d0, None, Lv3.data_ptr(), None, None, None))
+    assert torch.equal(Lv3, Lv)
+    hm = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=3, eps=0.1, hmc=True)
+    hplan = hm._plan()
+    assert L.l2hmc_small_propose(C.byref(hplan), x.data_ptr(), B, seed, d0, None, Lv3.data_ptr(), None, None, None) != 0
+
+
 def test_generic_dynamics_hmc_and_quadratic_gaussian(la):
     tgt = la.Gaussian(np.zeros(2), np.array([[1.0, 0.3], [0.3, 0.5]]))
     ot = ogen.Gaussian(np.zeros(2), np.array([[1.0, 0.3], [0.3, 0.5]]))
