@@ -360,70 +360,99 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       cxin[c * Cfg::CXIN + ((ii + 1) * LP + jj + 1) * 2 + mu] = src[c * SX + e];
     }
     __syncthreads();
-    for (int idx = tid; idx < kFM * L2 * L2 * F; idx += kFThreads) {
-      const int f = idx % F;
-      int rr = idx / F;
-      const int J = rr % L2;
-      rr /= L2;
-      const int I = rr % L2, c = rr / L2;
-      const float bias = b1[f];
-      float m = -INFINITY;
+    // conv1 + relu + pool.  A thread owns a PAIR of filters (2 fp, 2 fp + 1) of one pooled position: the pair's 18
+    // taps sit in registers for all of its positions (the workgroup size is a multiple of F / 2, so fp never
+    // changes), the 4 x 4 x 2 input patch under the 2 x 2 pooling window is read once (16 ds_read_b64 instead of
+    // 72 + 72 scalar reads), and every multiply-add is a v_pk_fma_f32 over the filter pair.
+    {
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      constexpr int FP = F / 2;
+      static_assert(kFThreads % FP == 0 && F % 2 == 0, "filter pairs must stay with their threads");
+      const int fp = tid % FP;
+      f32x2 k0[9], k1[9];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int i = 2 * I + a, j = 2 * J + bb;
-          float v0 = bias, v1 = bias;
-#pragma unroll
-          for (int di = 0; di < 3; ++di) {
-#pragma unroll
-            for (int dj = 0; dj < 3; ++dj) {
-              const float* px = cxin + c * Cfg::CXIN + ((i + di) * LP + j + dj) * 2;
-              const float x0 = px[0], x1 = px[1];
-              const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
-              v0 += x0 * k0 + x1 * k1;
-              v1 += x1 * k0;
-            }
-          }
-          m = fmaxf(m, fmaxf(v0, v1));
-        }
+      for (int t = 0; t < 9; ++t) {
+        k0[t] = *reinterpret_cast<const f32x2*>(w1 + (t * 2 + 0) * F + 2 * fp);
+        k1[t] = *reinterpret_cast<const f32x2*>(w1 + (t * 2 + 1) * F + 2 * fp);
       }
-      cp1[c * Cfg::CP1 + (I * L2P + J) * F + f] = fmaxf(m, 0.f);
+      const f32x2 bias = *reinterpret_cast<const f32x2*>(b1 + 2 * fp);
+      for (int idx = tid; idx < kFM * L2 * L2 * FP; idx += kFThreads) {
+        int rr = idx / FP;
+        const int J = rr % L2;
+        rr /= L2;
+        const int I = rr % L2, c = rr / L2;
+        f32x2 px[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+            px[a][bb] = *reinterpret_cast<const f32x2*>(cxin + c * Cfg::CXIN + ((2 * I + a) * LP + 2 * J + bb) * 2);
+        f32x2 m = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            f32x2 v0 = bias, v1 = bias;              // the two depth positions of conv_net.py's (3, 3, 2) filter
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+#pragma unroll
+              for (int dj = 0; dj < 3; ++dj) {
+                const f32x2 xx = px[a + di][bb + dj];
+                const f32x2 x0 = {xx[0], xx[0]}, x1 = {xx[1], xx[1]};
+                v0 += x0 * k0[di * 3 + dj] + x1 * k1[di * 3 + dj];
+                v1 += x1 * k0[di * 3 + dj];
+              }
+            }
+            m[0] = fmaxf(m[0], fmaxf(v0[0], v1[0]));
+            m[1] = fmaxf(m[1], fmaxf(v0[1], v1[1]));
+          }
+        }
+        *reinterpret_cast<f32x2*>(cp1 + c * Cfg::CP1 + (I * L2P + J) * F + 2 * fp) = f32x2{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f)};
+      }
     }
     __syncthreads();
-    for (int idx = tid; idx < kFM * L4 * L4 * F2; idx += kFThreads) {
-      const int g = idx % F2;
-      int rr = idx / F2;
-      const int J2 = rr % L4;
-      rr /= L4;
-      const int I2 = rr % L4, c = rr / L4;
-      const float bias = b2[g];
-      // 2x2 outputs of the pooling window share a 3x3 patch of the pooled conv1 map: per 4 input channels,
-      // 9 ds_read_b128 (patch, broadcast across the g lanes) + 16 weight reads feed 64 FMAs
-      float acc[2][2] = {{bias, bias}, {bias, bias}};
-      const float* pbase = cp1 + c * Cfg::CP1 + ((2 * I2) * L2P + 2 * J2) * F;
-      for (int ch4 = 0; ch4 < F; ch4 += 4) {
-        f32x4 w[3][3];
-  #pragma unroll
-        for (int wi = 0; wi < 3; ++wi)
-  #pragma unroll
-          for (int wj = 0; wj < 3; ++wj)
-            w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * L2P + wj) * F + ch4);
-  #pragma unroll
-        for (int di = 0; di < 2; ++di)
-  #pragma unroll
-          for (int dj = 0; dj < 2; ++dj)
-  #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              const float kw = w2[((di * 2 + dj) * F + ch4 + cc) * F2 + g];
-  #pragma unroll
-              for (int a = 0; a < 2; ++a)
-  #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) acc[a][bb] += w[a + di][bb + dj][cc] * kw;
-            }
+    // conv2 + relu + pool, again a pair of filters (2 gp, 2 gp + 1) per thread: the 2 x 2 outputs of the pooling
+    // window share a 3 x 3 patch of the pooled conv1 map -- per 4 input channels, 9 ds_read_b128 (patch) + 16
+    // ds_read_b64 (taps of the pair) feed 64 v_pk_fma_f32
+    {
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      constexpr int GP = F2 / 2;
+      for (int idx = tid; idx < kFM * L4 * L4 * GP; idx += kFThreads) {
+        const int gp = idx % GP;
+        int rr = idx / GP;
+        const int J2 = rr % L4;
+        rr /= L4;
+        const int I2 = rr % L4, c = rr / L4;
+        const f32x2 bias = *reinterpret_cast<const f32x2*>(b2 + 2 * gp);
+        f32x2 acc[2][2] = {{bias, bias}, {bias, bias}};
+        const float* pbase = cp1 + c * Cfg::CP1 + ((2 * I2) * L2P + 2 * J2) * F;
+        for (int ch4 = 0; ch4 < F; ch4 += 4) {
+          f32x4 w[3][3];
+#pragma unroll
+          for (int wi = 0; wi < 3; ++wi)
+#pragma unroll
+            for (int wj = 0; wj < 3; ++wj)
+              w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * L2P + wj) * F + ch4);
+#pragma unroll
+          for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                const f32x2 kw = *reinterpret_cast<const f32x2*>(w2 + ((di * 2 + dj) * F + ch4 + cc) * F2 + 2 * gp);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                  for (int bb = 0; bb < 2; ++bb) {
+                    const float xv = w[a + di][bb + dj][cc];
+                    acc[a][bb] += f32x2{xv, xv} * kw;
+                  }
+              }
+        }
+        const float m0 = fmaxf(fmaxf(acc[0][0][0], acc[0][1][0]), fmaxf(acc[1][0][0], acc[1][1][0]));
+        const float m1 = fmaxf(fmaxf(acc[0][0][1], acc[0][1][1]), fmaxf(acc[1][0][1], acc[1][1][1]));
+        *reinterpret_cast<f32x2*>(dst + c * SA + (I2 * L4 + J2) * F2 + 2 * gp) = f32x2{fmaxf(m0, 0.f), fmaxf(m1, 0.f)};
       }
-      const float m = fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[1][0], acc[1][1]));
-      dst[c * SA + (I2 * L4 + J2) * F2 + g] = fmaxf(m, 0.f);
     }
     __syncthreads();
   };
@@ -484,8 +513,10 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       int s1 = SX;
       if constexpr (CONV) {
         const float* cwn = cwl + (is_vnet ? 2 : 0) * Cfg::CW;
+        [[maybe_unused]] const unsigned long long tc0 = FT_NOW();
         if (l1 == 0 || l1 == 1 || l1 == 3) conv_features(in1, cwn, fa);            // first input (conv_v*)
         if (l1 != 2) conv_features(gs, cwn + Cfg::CW, fb);                          // second input (conv_x*)
+        FT_ADD(8, tc0);                                                             // (slot 8: conv front-end; also inside slot 0)
         src1 = fa;
         src2 = fb;
         s1 = SA;
