@@ -93,6 +93,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum over each 16-lane row (lanes 16 k .. 16 k + 15), returned in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_take<0xB1, 0xf>(v);
+  v += dpp_take<0x4E, 0xf>(v);
+  v += dpp_take<0x141, 0xf>(v);
+  v += dpp_take<0x140, 0xf>(v);
+  return v;
+}
+
 // sums over lanes 0..31 and 32..63 separately: valid in lanes 31 and 63 of the returned value
 __device__ __forceinline__ float wave_half_sums(float v) {
   v += dpp_take<0xB1, 0xf>(v);

@@ -91,14 +91,27 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
     b_ok[i] = (n0 + b_row[i]) < p.N;
   }
 
+  // Tile loads of the aligned path are UNCONDITIONAL and nothing consumes them before store_tile (after the k-tile's
+  // MFMAs): rows / columns past the end are clamped to the last valid one (their products land in accumulator rows /
+  // columns that are never stored), the source of a first-layer tile is a pointer select, and the column mask of the
+  // second input is multiplied in at store time.  (The earlier form -- loads under `if (k0 < K1) ... else ...` with
+  // the mask multiply right behind them -- made the compiler drain the load queue between the four A loads of
+  // every second-input tile: the first layer ran 15 % behind the same-shape hidden layer.)
   f32x4 ra[A_CH], rb[B_CH];
+  [[maybe_unused]] f32x4 rm[A_CH];
+  [[maybe_unused]] bool tile_masked = false;
+  int64_t a_grow[A_CH], b_grow[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) a_grow[i] = a_ok[i] ? m0 + a_row[i] : p.rows - 1;
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) b_grow[i] = b_ok[i] ? n0 + b_row[i] : p.N - 1;
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
+    if constexpr (RAGGED) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok[i]) {
-        if constexpr (RAGGED) {
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok[i]) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = k0 + a_kc[i] + j;
@@ -110,39 +123,51 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
               v[j] = t;
             }
           }
-        } else if (KIND == 2 || k0 < p.K1) {
-          v = *reinterpret_cast<const f32x4*>(p.A1 + (m0 + a_row[i]) * p.lda1 + k0 + a_kc[i]);
-        } else {
-          const int kk = k0 - p.K1 + a_kc[i];
-          v = *reinterpret_cast<const f32x4*>(p.A2 + (m0 + a_row[i]) * p.lda2 + kk);
-          if (p.cmask_f) {
-            const float* cm = a_dir[i] ? p.cmask_b : p.cmask_f;
-            v *= *reinterpret_cast<const f32x4*>(cm + kk);
-          }
         }
+        ra[i] = v;
       }
-      ra[i] = v;
-    }
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i]) {
-        if constexpr (RAGGED) {
+      for (int i = 0; i < B_CH; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b_ok[i]) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = k0 + b_kc[i] + j;
             if (k < p.K) v[j] = p.Wt[(int64_t)(n0 + b_row[i]) * p.K + k];
           }
-        } else {
-          v = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + b_row[i]) * p.K + k0 + b_kc[i]);
+        }
+        rb[i] = v;
+      }
+    } else {
+      const bool second = KIND != 2 && k0 >= p.K1;            // uniform
+      const float* abase = second ? p.A2 : p.A1;
+      const int64_t lda = second ? p.lda2 : p.lda1;
+      const int kk0 = second ? k0 - p.K1 : k0;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i)
+        ra[i] = *reinterpret_cast<const f32x4*>(abase + a_grow[i] * lda + kk0 + a_kc[i]);
+      if constexpr (KIND == 1) {
+        tile_masked = second && p.cmask_f != nullptr;
+        if (tile_masked) {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i)
+            rm[i] = *reinterpret_cast<const f32x4*>((a_dir[i] ? p.cmask_b : p.cmask_f) + kk0 + a_kc[i]);
         }
       }
-      rb[i] = v;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        rb[i] = *reinterpret_cast<const f32x4*>(p.Wt + b_grow[i] * p.K + k0 + b_kc[i]);
     }
   };
   auto store_tile = [&](int buf) {
     float* ab = lds + buf * STAGE;
     float* bb = ab + BM * LDK;
+    if constexpr (KIND == 1 && !RAGGED) {
+      if (tile_masked) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] *= rm[i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       *reinterpret_cast<f32x4*>(ab + a_row[i] * LDK + a_kc[i]) = ra[i];
@@ -372,10 +397,10 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     for (int e = 0; e < 4; ++e) {
       const int64_t row = m0 + wave * 16 + q * 4 + e;
       if (row >= p.rows || !cok) continue;
-      const float S = tanhf(acc[0][j][e] + b_s) * e_s;
+      const float S = fast_tanh(acc[0][j][e] + b_s) * e_s;
       const float T = acc[1][j][e] + b_t;
       float Q = acc[2][j][e] + b_q;
-      Q = (p.q_tanh ? tanhf(Q) : Q) * e_q;
+      Q = (p.q_tanh ? fast_tanh(Q) : Q) * e_q;
       const int64_t idx = row * p.D + col;
       if (p.mode == kHeadsMaterialise) {
         p.S[idx] = S;
@@ -389,8 +414,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
           const float g = p.g[idx], v = p.v[idx];
           const float s = (d ? -0.5f : 0.5f) * eps * S;
           const float tq = eps * Q;
-          const float kick = 0.5f * eps * (expf(tq) * g - T);
-          p.v[idx] = d ? expf(s) * (v + kick) : v * expf(s) - kick;
+          const float kick = 0.5f * eps * (fast_exp(tq) * g - T);
+          p.v[idx] = d ? fast_exp(s) * (v + kick) : v * fast_exp(s) - kick;
           ld[e] += s;
         } else {
           // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd)
@@ -398,8 +423,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
           const float x = p.x[idx], v = p.v[idx];
           const float s = (d ? -eps : eps) * S;
           const float tq = eps * Q;
-          const float drift = eps * (expf(tq) * v + T);
-          const float upd = d ? expf(s) * (x - drift) : x * expf(s) + drift;
+          const float drift = eps * (fast_exp(tq) * v + T);
+          const float upd = d ? fast_exp(s) * (x - drift) : x * fast_exp(s) + drift;
           p.x[idx] = keep * x + (1.f - keep) * upd;
           ld[e] += (1.f - keep) * s;
         }
@@ -410,11 +435,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     // reduce over the 16 lanes (columns) of each quarter; rows q*4+e stay apart
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float t = ld[e];
-      t += __shfl_xor(t, 8, 64);
-      t += __shfl_xor(t, 4, 64);
-      t += __shfl_xor(t, 2, 64);
-      t += __shfl_xor(t, 1, 64);
+      const float t = row16_sum(ld[e]);        // DPP on the VALU (four __shfl_xor would be ds_bpermute round trips)
       const int64_t row = m0 + wave * 16 + q * 4 + e;
       if (r == 0 && row < p.rows) p.ld_part[row * p.ncb + nt_id] += t;
     }

@@ -20,13 +20,19 @@ import l2hmc_amd as la  # noqa: E402
 
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    T = X = 8
-    D = 128
+    T = X = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    arch = sys.argv[3] if len(sys.argv) > 3 else 'generic'
+    D = 2 * T * X
     L = _lib.lib()
     L.l2hmc_debug_set_stamps.argtypes = [C.c_void_p, C.c_int]
     np.random.seed(106)
-    net = la.GenericNet(model_name='XNet', x_dim=D, num_hidden=4 * D, factor=2., name_scope='position',
-                        links_shape=(T, X, 2))
+    if arch == 'generic':
+        net = la.GenericNet(model_name='XNet', x_dim=D, num_hidden=4 * D, factor=2., name_scope='position',
+                            links_shape=(T, X, 2))
+    else:        # ConvNet3D as GaugeDynamics builds it (gauge_dynamics.py:121-143): F = T, H = 2 x_dim
+        net = la.ConvNet3D(model_name='XNet', _input_shape=(rows, T, X, 2), links_shape=(T, X, 2), x_dim=D, factor=2.,
+                           spatial_size=X, num_hidden=2 * D, num_filters=int(X), filter_sizes=[(3, 3, 2), (2, 2, 2)],
+                           name_scope='position', data_format='channels_last')
     a = torch.randn(rows, D, device="cuda")
     b = torch.rand(rows, D, device="cuda") * 6.28
     t = np.array([[0.3, 0.95]])

@@ -43,7 +43,7 @@ def gauge(name, L, B, N, eps, beta, arch, iters=5, fused=True):
                            eps_trainable=True, data_format='channels_last')
     dyn.fused = fused
     x = torch.as_tensor(lat.samples.reshape(B, -1), dtype=torch.float32, device="cuda")
-    dt = timeit(lambda: dyn(x, beta), warm=2, iters=iters)
+    dt = timeit(lambda: dyn(x, beta), warm=4, iters=iters)
     D = 2 * L * L
     macs = generic_macs(D, 4 * D) if arch == 'generic' else conv_macs(L, D, 2 * D, L)
     flops = 2 * B * N * 8 * macs
@@ -51,6 +51,8 @@ def gauge(name, L, B, N, eps, beta, arch, iters=5, fused=True):
           f"{flops/dt/1e12:6.1f} TFLOP/s executed ({flops/dt/1e12/157.3:.2f} of fp32 MFMA peak)", flush=True)
     del dyn, lat
     torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    time.sleep(0.3)       # the release of the big layered workspaces otherwise runs into the next configuration's timing
 
 
 def small(name, target, B, N, H):
