@@ -387,7 +387,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           const int e0 = 2 * s, er = 2 * (i * X + jp), ed = 2 * (ip * X + j);
           const float P = xc[e0] - xc[e0 + 1] - xc[er] + xc[ed + 1];
           const float Pu = uc[e0] - uc[e0 + 1] - uc[er] + uc[ed + 1];
-          sp[fc * SP + s] = cosf(P) * Pu;
+          float sn_, cs_;
+          fast_sincos(P, &sn_, &cs_);       // (the polynomial pair of common.h, ~1e-7: as in the forward stencil)
+          sp[fc * SP + s] = cs_ * Pu;
         }
         __syncthreads();
         const float* spc = sp + fc * SP;

@@ -87,7 +87,11 @@ def test_native_library_is_the_one_loaded(la):
 
 
 # ----------------------------------------------------------------- lattice
-@pytest.mark.parametrize("T,X,B", [(8, 8, 7), (8, 8, 1), (16, 16, 5), (32, 32, 3), (4, 6, 9), (17, 17, 2), (4, 4, 300)])
+# every lanes-per-chain class of the two-sites-per-thread kernel (32: 8x8, 4x16, 32x2; 64: 8x16; 128: 16x16; 256: 16x32,
+# 32x16; 512: 32x32, 16x64), ragged batches (partial workgroups), and shapes that take the general kernel
+@pytest.mark.parametrize("T,X,B", [(8, 8, 7), (8, 8, 1), (16, 16, 5), (32, 32, 3), (4, 6, 9), (17, 17, 2), (4, 4, 300),
+                                   (8, 16, 5), (16, 32, 3), (32, 16, 2), (4, 16, 11), (32, 2, 9), (16, 64, 2),
+                                   (8, 8, 1027), (64, 1, 3), (5, 8, 4)])
 def test_u1_action_force_observables(la, T, X, B):
     x = np.random.default_rng(1).uniform(-7, 7, (B, 2 * T * X)).astype(np.float32)
     o = la.u1_observables(x, T, X, beta=2.5, want_force=True)
