@@ -297,12 +297,17 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   float* b1 = w1 + 18 * F;
   float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice)
   float* b2 = w2 + 4 * F * F2;
+  L2HMC_STAMP(0);
   float* xin = b2 + F2;                            // [cpw][TP][XP][2]
   float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][F]
   float* dpre1 = p1 + cpw * T2P * X2P * F;         // [cpw][T2][X2][F]   gradient at the winning conv1 output
-  float* d2 = dpre1 + cpw * T2 * X2 * F;           // [cpw][T4][X4][2F]  gradient at the winning conv2 output
-  unsigned char* arg1 = reinterpret_cast<unsigned char*>(d2 + cpw * T4 * X4 * F2);   // [cpw][T2][X2][F]
-  unsigned char* arg2 = arg1 + cpw * T2 * X2 * F;                                    // [cpw][T4][X4][2F]
+  // dense gradient maps over the PRE-pooling outputs (the winner of a pooling cell carries its gradient, the other
+  // positions hold 0), with a zero halo so that the transposed convolutions below need no bounds checks:
+  float* G1 = dpre1 + cpw * T2 * X2 * F;           // [cpw][TP][XP][2 depths][F]   conv1 output (i, j) at (i + 1, j + 1)
+  float* G2 = G1 + cpw * TP * XP * 2 * F;          // [cpw][T2P][X2P][2F]          conv2 output (i2, j2) at (i2 + 1, j2 + 1)
+  const int nent = 18 * F + F + 4 * F * F2 + F2;   // compact gradient entries: w1 | b1 | w2 (dd = 0 slice) | b2
+  float* pw = G2 + cpw * T2P * X2P * F2;           // [cpw][nent] per-chain contributions
+  unsigned char* arg1 = reinterpret_cast<unsigned char*>(pw + cpw * nent);   // [cpw][T2][X2][F] winner of each cell
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * cpw;
   const int nrow = (int)min((int64_t)cpw, p.rows - row0);
@@ -316,8 +321,30 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
   }
   for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
-  for (int i = tid; i < cpw * TP * XP * 2; i += kConvThreads) xin[i] = 0.f;
-  for (int i = tid; i < cpw * T2P * X2P * F; i += kConvThreads) p1[i] = 0.f;
+  {
+    // xin | p1 | dpre1 | G1 | G2 are contiguous and each a multiple of four floats: one 16-byte sweep clears the halos
+    const int nz4 = (int)((G2 + cpw * T2P * X2P * F2) - xin) / 4;
+    for (int i = tid; i < nz4; i += kConvThreads) reinterpret_cast<f32x4*>(xin)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // this workgroup's gradient slot is read now and written at the very end: its round trip hides under the phases
+  const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
+  float* part = p.part + ((size_t)blockIdx.x * 2 + which) * psize;
+  auto slot_of = [&](int ent) -> size_t {                // slot layout: Keras kernels, dd = 1 rows of w2 stay 0
+    if (ent < 19 * F) return (size_t)ent;
+    if (ent < 19 * F + 4 * F * F2) {
+      const int e2 = ent - 19 * F;
+      const int g = e2 % F2, ch = (e2 / F2) % F, tap = e2 / (F2 * F);
+      return (size_t)19 * F + ((size_t)(tap * 2 + 0) * F + ch) * F2 + g;
+    }
+    return (size_t)19 * F + (size_t)16 * F * F + (ent - 19 * F - 4 * F * F2);
+  };
+  constexpr int kSlotRegs = 12;                          // entries per thread held across the kernel (3072 of them)
+  float slot_old[kSlotRegs];
+#pragma unroll
+  for (int k = 0; k < kSlotRegs; ++k) {
+    const int ent = tid + k * kConvThreads;
+    slot_old[k] = ent < nent ? part[slot_of(ent)] : 0.f;
+  }
   __syncthreads();
   const float* in = p.in + which * D;
   for (int i = tid; i < nrow * D; i += kConvThreads) {
@@ -328,6 +355,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
+  L2HMC_STAMP(1);
   // ---- phase 1: conv1 + pool1, remember the winner of each pooled cell
   const int n1 = nrow * T2 * X2 * F;
   for (int idx = tid; idx < n1; idx += kConvThreads) {
@@ -365,7 +393,8 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   }
   __syncthreads();
 
-  // ---- phase 2: conv2 + pool2 winners; gradient of the surviving features
+  L2HMC_STAMP(2);
+  // ---- phase 2: conv2 + pool2; the surviving feature's gradient goes to its winner in G2, zeros to the other three
   const int n2 = nrow * T4 * X4 * F2;
   for (int idx = tid; idx < n2; idx += kConvThreads) {
     const int g = idx % F2;
@@ -376,17 +405,25 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     const float bias = b2[g];
     float acc[2][2] = {{bias, bias}, {bias, bias}};
     const float* pbase = p1 + ((c * T2P + 2 * I2) * X2P + 2 * J2) * F;
-    for (int ch = 0; ch < F; ++ch) {
+    for (int ch4 = 0; ch4 < F; ch4 += 4) {
+      f32x4 w[3][3];
+#pragma unroll
+      for (int wi = 0; wi < 3; ++wi)
+#pragma unroll
+        for (int wj = 0; wj < 3; ++wj)
+          w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * X2P + wj) * F + ch4);
 #pragma unroll
       for (int di = 0; di < 2; ++di)
 #pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-          const float kw = w2[((di * 2 + dj) * F + ch) * F2 + g];
+        for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int cc = 0; cc < 4; ++cc) {
+            const float kw = w2[((di * 2 + dj) * F + ch4 + cc) * F2 + g];
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) acc[a][bb] += pbase[((a + di) * X2P + bb + dj) * F + ch] * kw;
-        }
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) acc[a][bb] += w[a + di][bb + dj][cc] * kw;
+          }
     }
     float m = -INFINITY;
     int code = 255;
@@ -395,125 +432,152 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
         if (acc[a][bb] > m) { m = acc[a][bb]; code = a * 2 + bb; }
-    const bool alive = m > 0.f;
-    arg2[idx] = (unsigned char)(alive ? code : 255);
-    d2[idx] = alive ? p.dfeat[(row0 + c) * p.ldf + which * (T4 * X4 * F2) + (I2 * X4 + J2) * F2 + g] : 0.f;
+    const float dv = m > 0.f ? p.dfeat[(row0 + c) * p.ldf + which * (T4 * X4 * F2) + (I2 * X4 + J2) * F2 + g] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+        G2[((c * T2P + 2 * I2 + a + 1) * X2P + 2 * J2 + bb + 1) * F2 + g] = (code == a * 2 + bb) ? dv : 0.f;
   }
   __syncthreads();
 
-  // ---- phase 3: gradient of the pooled conv1 map, gated by its own relu / winner
+  L2HMC_STAMP(3);
+  // ---- phase 3: transposed conv2 (dense, no winner tests): gradient of the pooled conv1 map, gated by its own relu /
+  // winner, then spread over the cell's eight pre-pooling outputs in G1.  conv2 output (i2, j2) reads p1(i2 + di,
+  // j2 + dj), so p1 cell (I, J) collects output (I - di, J - dj) through tap (di, dj).
   for (int idx = tid; idx < n1; idx += kConvThreads) {
     const int ch = idx % F;
     int r = idx / F;
     const int J = r % X2;
     r /= X2;
     const int I = r % T2, c = r / T2;
+    const int code = arg1[idx];
     float dp = 0.f;
-    if (arg1[idx] != 255) {
+    if (code != 255) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int di = 0; di < 2; ++di) {
+      for (int di = 0; di < 2; ++di)
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
-          const int i2 = I - di, j2 = J - dj;       // conv2 output whose tap (di, dj) reads p1[I, J]
-          if (i2 < 0 || j2 < 0) continue;
-          const int cell = ((c * T4 + (i2 >> 1)) * X4 + (j2 >> 1)) * F2;
-          const int want = (i2 & 1) * 2 + (j2 & 1);
+          const float* gq = G2 + ((c * T2P + I - di + 1) * X2P + J - dj + 1) * F2;
           const float* kw = w2 + ((di * 2 + dj) * F + ch) * F2;
-          for (int g = 0; g < F2; ++g)
-            if (arg2[cell + g] == want) dp += d2[cell + g] * kw[g];
+          for (int g4 = 0; g4 < F2; g4 += 4)
+            s4 += *reinterpret_cast<const f32x4*>(gq + g4) * *reinterpret_cast<const f32x4*>(kw + g4);
         }
-      }
+      dp = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
     dpre1[idx] = dp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int dep = 0; dep < 2; ++dep)
+          G1[(((c * TP + 2 * I + a + 1) * XP + 2 * J + bb + 1) * 2 + dep) * F + ch] =
+              (code == (a * 2 + bb) * 2 + dep) ? dp : 0.f;
   }
   __syncthreads();
 
-  // ---- phase 4: gradient of the raw input (zero padding: no periodic wrap, as the forward)
-  for (int i = tid; i < nrow * D; i += kConvThreads) {
-    const int c = i / D, e = i - c * D;
-    const int site = e >> 1, mu = e & 1;
+  L2HMC_STAMP(4);
+  // ---- phase 4: transposed conv1 (dense): gradient of the raw input, both link directions of a site per thread.
+  // conv1 output (i, j) reads x(i + di - 1, j + dj - 1) (zero padding: no periodic wrap, as the forward); depth 0
+  // sees (mu = 0, mu = 1) through (k0, k1) = w1[tap][dd = 0 | 1], depth 1 sees mu = 1 through k0.
+  for (int sidx = tid; sidx < nrow * T * X; sidx += kConvThreads) {
+    const int c = sidx / (T * X), site = sidx - c * (T * X);
     const int ip = site / X, jp = site - ip * X;
-    const int Ilo = max(ip - 1, 0) >> 1, Ihi = min(ip + 1, T - 1) >> 1;
-    const int Jlo = max(jp - 1, 0) >> 1, Jhi = min(jp + 1, X - 1) >> 1;
-    float gsum = 0.f;
-    for (int I = Ilo; I <= Ihi; ++I)
-      for (int J = Jlo; J <= Jhi; ++J) {
-        const int cell = ((c * T2 + I) * X2 + J) * F;
-        for (int f = 0; f < F; ++f) {
-          const int code = arg1[cell + f];
-          if (code == 255) continue;
-          const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
-          const int di = ip - (2 * I + a) + 1, dj = jp - (2 * J + bb) + 1;
-          if (di < 0 || di > 2 || dj < 0 || dj > 2) continue;
-          // output depth 0 reads (mu = 0, dd = 0) and (mu = 1, dd = 1); depth 1 reads (mu = 1, dd = 0) and padding
-          int dd;
-          if (depth == 0) dd = mu;
-          else if (mu == 1) dd = 0;
-          else continue;
-          gsum += dpre1[cell + f] * w1[((di * 3 + dj) * 2 + dd) * F + f];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int di = 0; di < 3; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 3; ++dj) {
+        const float* gq = G1 + ((c * TP + ip - di + 2) * XP + jp - dj + 2) * 2 * F;     // output (ip - di + 1, jp - dj + 1)
+        const float* k = w1 + (di * 3 + dj) * 2 * F;
+        for (int f4 = 0; f4 < F; f4 += 4) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gq + f4), g1 = *reinterpret_cast<const f32x4*>(gq + F + f4);
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + f4), k1 = *reinterpret_cast<const f32x4*>(k + F + f4);
+          a0 += g0 * k0;
+          a1 += g0 * k1 + g1 * k0;
         }
       }
-    p.din[(row0 + c) * p.ldd + which * D + e] = gsum;
+    float* o = p.din + (row0 + c) * p.ldd + which * D + 2 * site;
+    o[0] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    o[1] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
   }
 
-  // ---- phase 5: filter / bias gradients.  Work items are (chain, entry) pairs (every thread busy); each writes
-  // its chain's contribution to LDS, then one owner thread per entry adds the chains in order and accumulates
-  // into the workgroup's slot.
-  __syncthreads();
-  const int nent = 18 * F + F + 4 * F * F2 + F2;        // compact: w1 | b1 | w2 (dd = 0 slice) | b2
-  float* pw = reinterpret_cast<float*>(arg2 + ((cpw * T4 * X4 * F2 + 15) & ~15));   // [cpw][nent]
-  for (int item = tid; item < nrow * nent; item += kConvThreads) {
-    const int c = item / nent, ent = item - c * nent;
-    float s = 0.f;
-    if (ent < 18 * F) {
-      const int f = ent % F, dd = (ent / F) & 1, tap = ent / (2 * F);
+  L2HMC_STAMP(5);
+  // ---- phase 5: filter / bias gradients, every sum in a fixed order.  Each work item writes ONE chain's
+  // contribution to LDS; one owner thread per entry then adds the chains in order into the workgroup's slot.
+  //   w1 / b1: item (chain, tap, f) walks the chain's pooling cells of filter f once and feeds both dd entries;
+  //   w2 / b2: item (chain, tap, ch, 4 g) is a dense sum over the conv2 output positions (G2 holds zeros off-winner).
+  {
+    const int nw1 = nrow * 9 * F;
+    for (int item = tid; item < nw1; item += kConvThreads) {
+      const int f = item % F;
+      int r = item / F;
+      const int tap = r % 9, c = r / 9;
       const int di = tap / 3, dj = tap - di * 3;
+      float s0 = 0.f, s1 = 0.f;
       for (int I = 0; I < T2; ++I)
         for (int J = 0; J < X2; ++J) {
+          // branch-free: a dead cell (code 255) has dpre1 = 0 and decodes to a valid position
           const int cell = ((c * T2 + I) * X2 + J) * F + f;
-          const int code = arg1[cell];
-          if (code == 255) continue;
+          const int code = arg1[cell] & 7;
           const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
           const float* px = xin + ((c * TP + 2 * I + a + di) * XP + 2 * J + bb + dj) * 2;
-          const float xv = depth == 0 ? px[dd] : (dd == 0 ? px[1] : 0.f);
-          s += dpre1[cell] * xv;
+          const float dpv = dpre1[cell], x0 = px[0], x1 = px[1];
+          s0 += dpv * (depth ? x1 : x0);           // dd = 0: depth 0 reads mu = 0, depth 1 reads mu = 1
+          s1 += depth ? 0.f : dpv * x1;            // dd = 1: only depth 0 (mu = 1); depth 1 reads the padding
         }
-    } else if (ent < 19 * F) {
-      const int f = ent - 18 * F;
-      for (int cell = c * T2 * X2; cell < (c + 1) * T2 * X2; ++cell) s += dpre1[cell * F + f];
-    } else if (ent < 19 * F + 4 * F * F2) {
-      const int e2 = ent - 19 * F;
-      const int g = e2 % F2, ch = (e2 / F2) % F, tap = e2 / (F2 * F);
-      const int di = tap >> 1, dj = tap & 1;
-      for (int I2 = 0; I2 < T4; ++I2)
-        for (int J2 = 0; J2 < X4; ++J2) {
-          const int cell = ((c * T4 + I2) * X4 + J2) * F2 + g;
-          const int code = arg2[cell];
-          if (code == 255) continue;
-          const int i2 = 2 * I2 + (code >> 1), j2 = 2 * J2 + (code & 1);
-          s += d2[cell] * p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
-        }
-    } else {
-      const int g = ent - 19 * F - 4 * F * F2;
-      for (int cell = c * T4 * X4; cell < (c + 1) * T4 * X4; ++cell) s += d2[cell * F2 + g];
+      pw[c * nent + (tap * 2 + 0) * F + f] = s0;
+      pw[c * nent + (tap * 2 + 1) * F + f] = s1;
     }
-    pw[item] = s;
+    for (int item = tid; item < nrow * F; item += kConvThreads) {
+      const int f = item % F, c = item / F;
+      float sb = 0.f;
+      for (int cell = c * T2 * X2; cell < (c + 1) * T2 * X2; ++cell) sb += dpre1[cell * F + f];
+      pw[c * nent + 18 * F + f] = sb;
+    }
+    const int g4n = F2 / 4;
+    const int nw2 = nrow * 4 * F * g4n;
+    for (int item = tid; item < nw2; item += kConvThreads) {
+      const int g4 = (item % g4n) * 4;
+      int r = item / g4n;
+      const int ch = r % F;
+      r /= F;
+      const int tap = r % 4, c = r / 4;
+      const int di = tap >> 1, dj = tap & 1;
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+      for (int i2 = 0; i2 < T2; ++i2)
+        for (int j2 = 0; j2 < X2; ++j2)
+          s4 += *reinterpret_cast<const f32x4*>(G2 + ((c * T2P + i2 + 1) * X2P + j2 + 1) * F2 + g4) *
+                p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
+      *reinterpret_cast<f32x4*>(pw + c * nent + 19 * F + (tap * F + ch) * F2 + g4) = s4;
+    }
+    for (int item = tid; item < nrow * F2; item += kConvThreads) {
+      const int g = item % F2, c = item / F2;
+      float sb = 0.f;
+      for (int i2 = 0; i2 < T2; ++i2)
+        for (int j2 = 0; j2 < X2; ++j2) sb += G2[((c * T2P + i2 + 1) * X2P + j2 + 1) * F2 + g];
+      pw[c * nent + 19 * F + 4 * F * F2 + g] = sb;
+    }
   }
   __syncthreads();
-  const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
-  float* part = p.part + ((size_t)blockIdx.x * 2 + which) * psize;
-  for (int ent = tid; ent < nent; ent += kConvThreads) {
-    float s = 0.f;
-    for (int c = 0; c < nrow; ++c) s += pw[c * nent + ent];
-    size_t dst;                                          // slot layout: Keras kernels, dd = 1 rows of w2 stay 0
-    if (ent < 19 * F) dst = ent;
-    else if (ent < 19 * F + 4 * F * F2) {
-      const int e2 = ent - 19 * F;
-      const int g = e2 % F2, ch = (e2 / F2) % F, tap = e2 / (F2 * F);
-      dst = (size_t)19 * F + ((size_t)(tap * 2 + 0) * F + ch) * F2 + g;
-    } else dst = (size_t)19 * F + (size_t)16 * F * F + (ent - 19 * F - 4 * F * F2);
-    part[dst] += s;
+  L2HMC_STAMP(6);
+#pragma unroll
+  for (int k = 0; k < kSlotRegs; ++k) {
+    const int ent = tid + k * kConvThreads;
+    if (ent < nent) {
+      float sum = 0.f;
+      for (int c = 0; c < nrow; ++c) sum += pw[c * nent + ent];
+      part[slot_of(ent)] = slot_old[k] + sum;
+    }
   }
+  for (int ent = tid + kSlotRegs * kConvThreads; ent < nent; ent += kConvThreads) {     // wider filter sets
+    float sum = 0.f;
+    for (int c = 0; c < nrow; ++c) sum += pw[c * nent + ent];
+    part[slot_of(ent)] += sum;
+  }
+  L2HMC_STAMP(7);
 }
 
 size_t conv3d_bwd_part_floats(int F) { return (size_t)18 * F + F + (size_t)16 * F * F + 2 * F; }
@@ -529,12 +593,19 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
                 "conv3d front-end backward: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   a.cpw = conv3d_cpw(a.T, a.X, a.F);
-  const size_t cells1 = (size_t)a.cpw * (a.T / 2) * (a.X / 2) * a.F, cells2 = (size_t)a.cpw * (a.T / 4) * (a.X / 4) * 2 * a.F;
-  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
-                                      (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
-                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F + cells1 + cells2 +
-                                      (size_t)a.cpw * (19 * a.F + 8 * a.F * a.F + 2 * a.F)) +
-                     align_up(cells1, 1) + align_up(cells2, 16) + 16;
+#ifdef L2HMC_STAMPS
+  a.stamps = g_stamp_cls == 6 ? g_stamp_buf : nullptr;
+#endif
+  const size_t F = a.F, F2 = 2 * F, cpw = a.cpw, TP = a.T + 2, XP = a.X + 2, T2 = a.T / 2, X2 = a.X / 2;
+  const size_t cells1 = cpw * T2 * X2 * F, nent = 18 * F + F + 4 * F * F2 + F2;
+  const size_t lds = sizeof(float) * (18 * F + F + 4 * F * F2 + F2 +           // filters
+                                      cpw * TP * XP * 2 +                       // xin
+                                      cpw * (T2 + 1) * (X2 + 1) * F +           // p1
+                                      cells1 +                                  // dpre1
+                                      cpw * TP * XP * 2 * F +                   // G1
+                                      cpw * (T2 + 1) * (X2 + 1) * F2 +          // G2
+                                      cpw * nent) +                             // pw
+                     align_up(cells1, 16);                                      // arg1
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
   static DeviceOnce attr_once;

@@ -97,6 +97,7 @@ struct ConvBwdArgs {
   float* part;                           // [workgroups][2][conv3d_bwd_part_floats(F)], +=
   int64_t rows;
   int cpw;
+  unsigned long long* stamps;            // diagnostic builds only (class 6): phase boundaries of workgroup x
 };
 size_t conv3d_bwd_part_floats(int F);
 int conv3d_cpw(int T, int X, int F);
