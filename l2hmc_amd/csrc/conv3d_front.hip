@@ -283,8 +283,11 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
 // ([workgroup][input][18F | F | 16F^2 (Keras layout, dd = 1 rows stay 0) | 2F]); the same workgroup
 // sees the same chains in every call, and the slots are summed in order afterwards.
 // =====================================================================================
+// (latency-bound phases want resident waves: with the tap loop of phase 4 unrolled over one axis only the (8, 8)
+// instance needs 80 registers -- fully unrolled it took 242, i.e. two workgroups per CU)
 template <int FT, int LT>
-__global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdArgs p) {
+__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void conv3d_front_bwd_kernel(
+    ConvBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;
   const int T = LT ? LT : p.T, X = LT ? LT : p.X, F = FT ? FT : p.F, F2 = 2 * F;
@@ -303,11 +306,14 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
   float* dpre1 = p1 + cpw * T2P * X2P * F;         // [cpw][T2][X2][F]   gradient at the winning conv1 output
   // dense gradient maps over the PRE-pooling outputs (the winner of a pooling cell carries its gradient, the other
   // positions hold 0), with a zero halo so that the transposed convolutions below need no bounds checks:
-  float* G1 = dpre1 + cpw * T2 * X2 * F;           // [cpw][TP][XP][2 depths][F]   conv1 output (i, j) at (i + 1, j + 1)
-  float* G2 = G1 + cpw * TP * XP * 2 * F;          // [cpw][T2P][X2P][2F]          conv2 output (i2, j2) at (i2 + 1, j2 + 1)
+  // (the two depths of a position share one pooling cell, so at most one of them is the winner: G1 keeps ONE value
+  //  per (position, filter) and dep1 says which depth it belongs to -- half the LDS, more resident workgroups)
+  float* G1 = dpre1 + cpw * T2 * X2 * F;           // [cpw][TP][XP][F]    conv1 output (i, j) at (i + 1, j + 1)
   const int nent = 18 * F + F + 4 * F * F2 + F2;   // compact gradient entries: w1 | b1 | w2 (dd = 0 slice) | b2
-  float* pw = G2 + cpw * T2P * X2P * F2;           // [cpw][nent] per-chain contributions
-  unsigned char* arg1 = reinterpret_cast<unsigned char*>(pw + cpw * nent);   // [cpw][T2][X2][F] winner of each cell
+  float* G2 = G1 + cpw * max(TP * XP * F, nent);   // [cpw][T2P][X2P][2F] conv2 output (i2, j2) at (i2 + 1, j2 + 1)
+  float* pw = G1;                                  // [cpw][nent] per-chain contributions: phase 5, when G1 is dead
+  unsigned char* arg1 = reinterpret_cast<unsigned char*>(G2 + cpw * T2P * X2P * F2);   // [cpw][T2][X2][F] winners
+  unsigned char* dep1 = arg1 + ((cpw * T2 * X2 * F + 15) & ~15);                      // [cpw][TP][XP][F] depth of G1
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * cpw;
   const int nrow = (int)min((int64_t)cpw, p.rows - row0);
@@ -338,7 +344,8 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     }
     return (size_t)19 * F + (size_t)16 * F * F + (ent - 19 * F - 4 * F * F2);
   };
-  constexpr int kSlotRegs = 12;                          // entries per thread held across the kernel (3072 of them)
+  // entries per thread held across the kernel
+  constexpr int kSlotRegs = FT > 0 ? (18 * FT + FT + 8 * FT * FT + 2 * FT + kConvThreads - 1) / kConvThreads : 12;
   float slot_old[kSlotRegs];
 #pragma unroll
   for (int k = 0; k < kSlotRegs; ++k) {
@@ -470,11 +477,11 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int dep = 0; dep < 2; ++dep)
-          G1[(((c * TP + 2 * I + a + 1) * XP + 2 * J + bb + 1) * 2 + dep) * F + ch] =
-              (code == (a * 2 + bb) * 2 + dep) ? dp : 0.f;
+      for (int bb = 0; bb < 2; ++bb) {
+        const int pos = ((c * TP + 2 * I + a + 1) * XP + 2 * J + bb + 1) * F + ch;
+        G1[pos] = ((code >> 1) == a * 2 + bb) ? dp : 0.f;       // (code 255 >> 1 matches nothing; dp is 0 then anyway)
+        dep1[pos] = (unsigned char)(code & 1);
+      }
   }
   __syncthreads();
 
@@ -486,17 +493,22 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     const int c = sidx / (T * X), site = sidx - c * (T * X);
     const int ip = site / X, jp = site - ip * X;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int di = 0; di < 3; ++di)
 #pragma unroll
       for (int dj = 0; dj < 3; ++dj) {
-        const float* gq = G1 + ((c * TP + ip - di + 2) * XP + jp - dj + 2) * 2 * F;     // output (ip - di + 1, jp - dj + 1)
+        const int pos = ((c * TP + ip - di + 2) * XP + jp - dj + 2) * F;                // output (ip - di + 1, jp - dj + 1)
         const float* k = w1 + (di * 3 + dj) * 2 * F;
         for (int f4 = 0; f4 < F; f4 += 4) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gq + f4), g1 = *reinterpret_cast<const f32x4*>(gq + F + f4);
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(G1 + pos + f4);
+          const unsigned dm = *reinterpret_cast<const unsigned*>(dep1 + pos + f4);        // four depth bytes
           const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + f4), k1 = *reinterpret_cast<const f32x4*>(k + F + f4);
-          a0 += g0 * k0;
-          a1 += g0 * k1 + g1 * k0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool d1 = (dm >> (8 * e)) & 1u;
+            a0[e] += d1 ? 0.f : gv[e] * k0[e];                  // depth 0 -> mu = 0 through k0
+            a1[e] += gv[e] * (d1 ? k0[e] : k1[e]);              // depth 0 -> mu = 1 through k1, depth 1 -> mu = 1 through k0
+          }
         }
       }
     float* o = p.din + (row0 + c) * p.ldd + which * D + 2 * site;
@@ -504,6 +516,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_bwd_kernel(ConvBwdA
     o[1] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
   }
 
+  __syncthreads();                   // pw aliases G1
   L2HMC_STAMP(5);
   // ---- phase 5: filter / bias gradients, every sum in a fixed order.  Each work item writes ONE chain's
   // contribution to LDS; one owner thread per entry then adds the chains in order into the workgroup's slot.
@@ -602,10 +615,9 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
                                       cpw * TP * XP * 2 +                       // xin
                                       cpw * (T2 + 1) * (X2 + 1) * F +           // p1
                                       cells1 +                                  // dpre1
-                                      cpw * TP * XP * 2 * F +                   // G1
-                                      cpw * (T2 + 1) * (X2 + 1) * F2 +          // G2
-                                      cpw * nent) +                             // pw
-                     align_up(cells1, 16);                                      // arg1
+                                      cpw * (TP * XP * F > nent ? TP * XP * F : nent) +   // G1, later pw
+                                      cpw * (T2 + 1) * (X2 + 1) * F2) +         // G2
+                     align_up(cells1, 16) + align_up(cpw * TP * XP * F, 16);    // arg1, dep1
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
   static DeviceOnce attr_once;
