@@ -274,18 +274,20 @@ def test_train_loop_anneals_beta_and_keeps_samples_wrapped():
     assert tr.global_step == 5 and len(set(out["eps"])) > 1                                  # eps is being trained
 
 
-@pytest.mark.parametrize("N,eps,B,regime", [(2, 0.1, 9, "mild"), (3, 0.15, 5, "stress")])
-def test_conv3d_loss_gradients_match_autograd(N, eps, B, regime):
-    """ConvNet3D (the reference's CLI-default architecture, conv_net.py:247-280) at the 8x8 benchmark lattice:
-    gradients of the Conv3D kernels / biases (through both max-pools and relus), the dense trunk and eps."""
-    tr, tm, x, z, dx, dz = _setup(8, N, eps, B, regime, arch='conv3D')
+@pytest.mark.parametrize("L,N,eps,B,regime", [(8, 2, 0.1, 9, "mild"), (8, 3, 0.15, 5, "stress"),
+                                              (16, 1, 0.1, 3, "mild")])      # cfg 4's F = 16, 16x16 kernel instances
+def test_conv3d_loss_gradients_match_autograd(L, N, eps, B, regime):
+    """ConvNet3D (the reference's CLI-default architecture, conv_net.py:247-280) at the 8x8 benchmark lattice and at
+    cfg 4's 16x16: gradients of the Conv3D kernels / biases (through both max-pools and relus), the dense trunk and
+    eps."""
+    tr, tm, x, z, dx, dz = _setup(L, N, eps, B, regime, arch='conv3D')
     loss, *_ = tr.calc_loss_and_grads(x, 2.5, z=z, draws_x=dx, draws_z=dz)
     want_loss, _ = _ref_grads(tm, x, z, dx, dz, 2.5, 'cos_diff')
     assert abs(float(loss) - want_loss) <= 2e-4 * max(1., abs(want_loss))
     worst = _compare(tr, tm)
     # the dd = 1 slice of the second kernel only multiplies padding
     gv = tr.grad_views()
-    assert float(gv["xnet"]["w2_a"].reshape(2, 2, 2, 8, 16)[:, :, 1].abs().max()) == 0.0
+    assert float(gv["xnet"]["w2_a"].reshape(2, 2, 2, L, 2 * L)[:, :, 1].abs().max()) == 0.0
     assert "xnet.w1_a" in worst and "vnet.b2_b" in worst
 
 
