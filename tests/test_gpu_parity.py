@@ -960,6 +960,23 @@ def test_generic_dynamics_in_three_dimensions(la):
         Lx, Lv, px, outs = la.propose(x, dyn, init_v=v0f, do_mh_step=True, init_v_backward=v0b, dir_bits=bits, u=u)
         want = od.propose(x, orc, v0f, v0b, bits, u=u, do_mh_step=True)
         assert H.relerr(np_(Lx), want[0]) < TOL_OP and np.abs(np_(px) - want[2]).max() < TOL_P
+        # the one-launch propose (run-time-dimension instance, three-component target: LDS-resident parameters)
+        # against the piecewise path on the same library streams, bit for bit
+        from l2hmc_amd import _lib
+        Lh, d0 = _lib.lib(), 20
+
+        def fill(fn, n, off):
+            out = torch.empty(n, device="cuda")
+            _lib.check(fn(out.data_ptr(), n, dyn._seed, off, None))
+            return out
+        fb = (fill(Lh.l2hmc_fill_uniform, B, d0) >= 0.5).float()
+        fvf = fill(Lh.l2hmc_fill_normal, 3 * B, d0 + 1).reshape(B, 3)
+        fvb = fill(Lh.l2hmc_fill_normal, 3 * B, d0 + 2).reshape(B, 3)
+        fu = fill(Lh.l2hmc_fill_uniform, B, d0 + 3)
+        pLx, _, ppx, pouts = la.propose(x, dyn, init_v=fvf, do_mh_step=True, init_v_backward=fvb, dir_bits=fb, u=fu)
+        dyn._draws = d0
+        oLx, _, opx, oouts = la.propose(x, dyn, do_mh_step=True)
+        assert torch.equal(oLx, pLx) and torch.equal(opx, ppx) and torch.equal(oouts[0], pouts[0])
 
 
 @pytest.mark.parametrize("T,X", [(4, 16), (16, 4), (2, 32)])
