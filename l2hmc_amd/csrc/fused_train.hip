@@ -441,6 +441,291 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
   }
 }
 
+// =====================================================================================================
+// ONE network call of the reverse pass in one launch, for plans whose front-end keeps the reverse pass layered
+// (ConvNet3D: its front-end's reverse pass wants many resident waves, conv3d_front.hip).  Replaces, per call,
+// update_bwd_kernel + three gemm_relu launches of a few GFLOP each (one workgroup per CU: 12-16 us each,
+// latency-bound) by the element-wise phase and the three streamed products of the whole-trajectory kernel above on
+// 16 rows per workgroup: d loss / d (x, v) come from and go back to HBM, the relu gates are read from the taped
+// h1 / h2 rows (the forward kernel's mask words follow ITS wave count), the first layer's input gradient
+// (d loss / d features) goes out for conv3d_front_bwd_kernel, coefficient and step-size partials accumulate (+=)
+// in the workgroup's slots.  Same arithmetic and summation order per element as the layered kernels.
+// =====================================================================================================
+
+template <int D, int H, int K1>
+struct TrunkBwdCfg {
+  static constexpr int SO = 3 * D + 8, SH = H + 8;
+  static constexpr int NT1 = H / (16 * kFWaves), NT3 = K1 / (16 * kFWaves);
+  static constexpr int KCO = 3 * D / 16, KCH = H / 16;
+  static constexpr size_t P1 = (size_t)3 * D * H, P2 = (size_t)H * H;
+  static constexpr int LDS_FLOATS = kFM * SO + 2 * kFM * SH + 2 * D + kFM + 8;
+  static_assert(NT1 >= 1 && NT3 >= 1 && kTPC * 8 == D, "tile / thread mapping");
+};
+
+template <int D, int H, int K1>
+__global__ __launch_bounds__(kFThreads) void gauge_trunk_bwd_kernel(TrunkBwdArgs p) {
+  using Cfg = TrunkBwdCfg<D, H, K1>;
+  constexpr int SO = Cfg::SO, SH = Cfg::SH, NT1 = Cfg::NT1, NT3 = Cfg::NT3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dos = lds;                       // [16][SO] head pre-activation gradients
+  float* d2s = dos + kFM * SO;            // [16][SH]
+  float* d1s = d2s + kFM * SH;            // [16][SH]
+  float* ec = d1s + kFM * SH;             // exp(cs) exp(cq)  [2][D]
+  int* sdir = reinterpret_cast<int*>(ec + 2 * D);      // [16]
+  float* red = reinterpret_cast<float*>(sdir + kFM);   // [8]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int64_t row0 = (int64_t)blockIdx.x * kFM;
+  const int nrow = (int)min((int64_t)kFM, p.rows - row0);
+  const float eps = p.eps;
+  const int fc = tid / kTPC, fl = tid % kTPC;      // chain, lane-in-chain
+  const int c0 = fl * 8;                           // this thread's 8 columns in the element-wise phase
+  const bool live = fc < nrow;
+  const bool is_v = p.mode == 1;
+
+  for (int i = tid; i < D; i += kFThreads) {
+    ec[i] = expf(p.cs[i]);
+    ec[D + i] = expf(p.cq[i]);
+  }
+  if (tid < kFM) sdir[tid] = (tid < nrow && p.dir) ? p.dir[row0 + tid] : 0;
+  __syncthreads();
+  const int d = sdir[fc];
+  const int64_t grow = row0 + (live ? fc : 0);     // (dead rows read row 0 of the tile and write nothing)
+  const float dl = live ? p.dld[grow] : 0.f;
+
+  // ---- phase A: the sub-update, element-wise (gauge_dynamics.py:486-590 differentiated; update_bwd_kernel's math)
+  float acs[8], acq[8], deps = 0.f;
+  {
+    float S[8], Tt[8], Q[8], st[8], ia[8], ib[8], u[8], uv[8];
+    const float* sq = p.stq + grow * D + c0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 vS = *reinterpret_cast<const f32x4*>(sq + 4 * h);
+      const f32x4 vT = *reinterpret_cast<const f32x4*>(sq + p.plane + 4 * h);
+      const f32x4 vQ = *reinterpret_cast<const f32x4*>(sq + 2 * p.plane + 4 * h);
+      const f32x4 vst = *reinterpret_cast<const f32x4*>(p.st + grow * D + c0 + 4 * h);
+      const f32x4 va = *reinterpret_cast<const f32x4*>(p.in + grow * (2 * D) + c0 + 4 * h);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + grow * (2 * D) + D + c0 + 4 * h);
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(p.dx + grow * D + c0 + 4 * h);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.dv + grow * D + c0 + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        S[4 * h + k] = vS[k]; Tt[4 * h + k] = vT[k]; Q[4 * h + k] = vQ[k]; st[4 * h + k] = vst[k];
+        ia[4 * h + k] = va[k]; ib[4 * h + k] = vb[k]; u[4 * h + k] = vx[k]; uv[4 * h + k] = vv[k];
+      }
+    }
+    float o_s[8], o_t[8], o_q[8], ndx[8], ndv[8], ndg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + k;
+      const float eq = expf(eps * Q[k]);
+      float dS, dT, dQ;
+      ndx[k] = u[k]; ndv[k] = uv[k]; ndg[k] = 0.f;
+      if (is_v) {
+        // st = v before the kick, ib = force
+        const float vv = st[k], gg = ib[k], uu = uv[k], he = 0.5f * eps;
+        if (!d) {
+          const float es = expf(he * S[k]);
+          const float ds = uu * vv * es + dl;
+          ndv[k] = uu * es;
+          dS = ds * he; dT = uu * he; dQ = -uu * he * eq * gg * eps;
+          ndg[k] = -uu * he * eq;
+          deps += ds * 0.5f * S[k] - uu * 0.5f * (eq * gg - Tt[k]) - uu * he * gg * eq * Q[k];
+        } else {
+          const float es = expf(-he * S[k]);
+          const float kick = he * (eq * gg - Tt[k]);
+          const float vp = es * (vv + kick);
+          const float dw = uu * es;
+          const float ds = uu * vp + dl;
+          ndv[k] = dw;
+          dS = -he * ds; dT = -dw * he; dQ = dw * he * eq * gg * eps;
+          ndg[k] = dw * he * eq;
+          deps += -0.5f * S[k] * ds + dw * 0.5f * (eq * gg - Tt[k]) + dw * he * gg * eq * Q[k];
+        }
+      } else {
+        // st = x before the update, ia = v
+        const float kk = (d ? p.keep_b : p.keep_f)[c], mi = 1.f - kk;
+        const float xx = st[k], vv = ia[k], uu = u[k];
+        const float dy = mi * uu;
+        if (!d) {
+          const float es = expf(eps * S[k]);
+          const float ds = dy * xx * es + dl * mi;
+          ndx[k] = kk * uu + dy * es;
+          ndv[k] = uv[k] + dy * eps * eq;
+          dS = eps * ds; dT = dy * eps; dQ = dy * eps * eq * vv * eps;
+          deps += ds * S[k] + dy * (eq * vv + Tt[k]) + dy * eps * vv * eq * Q[k];
+        } else {
+          const float es = expf(-eps * S[k]);
+          const float w = xx - eps * (eq * vv + Tt[k]);
+          const float dw = dy * es;
+          const float ds = dy * (es * w) + dl * mi;
+          ndx[k] = kk * uu + dw;
+          ndv[k] = uv[k] - dw * eps * eq;
+          dS = -eps * ds; dT = -dw * eps; dQ = -dw * eps * eq * vv * eps;
+          deps += -S[k] * ds - dw * (eq * vv + Tt[k]) - dw * eps * vv * eq * Q[k];
+        }
+      }
+      // through tanh(.) * exp(coeff) (generic_net.py:139-144)
+      const float es_ = ec[c], eq_ = ec[D + c];
+      const float th = S[k] / es_;
+      float daq = dQ * eq_;
+      if (p.q_tanh) {
+        const float tq = Q[k] / eq_;
+        daq *= 1.f - tq * tq;
+      }
+      o_s[k] = dS * es_ * (1.f - th * th);
+      o_t[k] = dT;
+      o_q[k] = daq;
+      acs[k] = dS * S[k];
+      acq[k] = dQ * Q[k];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 vs_ = {o_s[4 * h], o_s[4 * h + 1], o_s[4 * h + 2], o_s[4 * h + 3]};
+      const f32x4 vt_ = {o_t[4 * h], o_t[4 * h + 1], o_t[4 * h + 2], o_t[4 * h + 3]};
+      const f32x4 vq_ = {o_q[4 * h], o_q[4 * h + 1], o_q[4 * h + 2], o_q[4 * h + 3]};
+      float* lo = dos + fc * SO + c0 + 4 * h;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(lo) = live ? vs_ : z;
+      *reinterpret_cast<f32x4*>(lo + D) = live ? vt_ : z;
+      *reinterpret_cast<f32x4*>(lo + 2 * D) = live ? vq_ : z;
+      if (live) {
+        float* go = p.dout + grow * (3 * D) + c0 + 4 * h;
+        *reinterpret_cast<f32x4*>(go) = vs_;
+        *reinterpret_cast<f32x4*>(go + D) = vt_;
+        *reinterpret_cast<f32x4*>(go + 2 * D) = vq_;
+        *reinterpret_cast<f32x4*>(p.dx + grow * D + c0 + 4 * h) = f32x4{ndx[4 * h], ndx[4 * h + 1], ndx[4 * h + 2], ndx[4 * h + 3]};
+        *reinterpret_cast<f32x4*>(p.dv + grow * D + c0 + 4 * h) = f32x4{ndv[4 * h], ndv[4 * h + 1], ndv[4 * h + 2], ndv[4 * h + 3]};
+        if (is_v)
+          *reinterpret_cast<f32x4*>(p.dg + grow * D + c0 + 4 * h) = f32x4{ndg[4 * h], ndg[4 * h + 1], ndg[4 * h + 2], ndg[4 * h + 3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  const float* pk = p.pk;
+  const float* wpb1 = pk + (size_t)wave * Cfg::KCO * NT1 * 256 + lane * 4;
+  const float* wpb2 = pk + Cfg::P1 + (size_t)wave * Cfg::KCH * NT1 * 256 + lane * 4;
+  const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KCH * NT3 * 256 + lane * 4;
+  const bool rlive = r < nrow;
+  const int64_t rrow = row0 + (rlive ? r : 0);    // lane (q, r): row r, four consecutive columns (fused_common.h)
+  // ---- phase B: delta2 = (dout . Whd) gated by h2 > 0
+  BRing<NT1, 4> R2;
+  {
+    BRing<NT1, 4> R1;
+    ring_prime<NT1, 4>(R1, wpb1);
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a = dos + r * SO + q * 4;
+    stream_layer<NT1, Cfg::KCO, 4>(
+        R1, wpb1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+    ring_prime<NT1, 4>(R2, wpb2);
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int cc = (wave * NT1 + t) * 16 + q * 4;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h2 + rrow * H + cc);
+      f32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (rlive && hv[e] > 0.f) ? acc[t][e] : 0.f;
+      *reinterpret_cast<f32x4*>(d2s + r * SH + cc) = g;
+      if (rlive) *reinterpret_cast<f32x4*>(p.d2 + rrow * H + cc) = g;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: delta1 = (delta2 . Wh) gated by h1 > 0
+  BRing<NT3, 4> R3;
+  {
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a = d2s + r * SH + q * 4;
+    stream_layer<NT1, Cfg::KCH, 4>(
+        R2, wpb2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+    ring_prime<NT3, 4>(R3, wpb3);
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int cc = (wave * NT1 + t) * 16 + q * 4;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h1 + rrow * H + cc);
+      f32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (rlive && hv[e] > 0.f) ? acc[t][e] : 0.f;
+      *reinterpret_cast<f32x4*>(d1s + r * SH + cc) = g;
+      if (rlive) *reinterpret_cast<f32x4*>(p.d1 + rrow * H + cc) = g;
+    }
+  }
+  __syncthreads();
+  // ---- phase D: d loss / d (first-layer inputs) = delta1 . W1, straight to HBM
+  {
+    f32x4 acc[NT3];
+#pragma unroll
+    for (int t = 0; t < NT3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a = d1s + r * SH + q * 4;
+    stream_layer<NT3, Cfg::KCH, 4>(
+        R3, wpb3, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+    if (rlive) {
+#pragma unroll
+      for (int t = 0; t < NT3; ++t)
+        *reinterpret_cast<f32x4*>(p.dfeat + rrow * K1 + (wave * NT3 + t) * 16 + q * 4) = acc[t];
+    }
+  }
+  // ---- coefficient / step-size partials: sum over the tile's chains in order, += into the workgroup's slots
+  auto col_reduce = [&](const float (&a8)[8], float* out) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d2s[fc * SH + c0 + k] = live ? a8[k] : 0.f;
+    __syncthreads();
+    if (tid < D) {
+      float sum = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < kFM; ++rr) sum += d2s[rr * SH + tid];
+      out[(size_t)blockIdx.x * D + tid] += sum;
+    }
+  };
+  col_reduce(acs, p.dcs_part);
+  col_reduce(acq, p.dcq_part);
+  deps = live ? deps : 0.f;
+  deps = wave_sum(deps);
+  __syncthreads();
+  if (lane == 0) red[wave] = deps;
+  __syncthreads();
+  if (tid == 0) {
+    float sum = 0.f;
+    for (int w = 0; w < kFWaves; ++w) sum += red[w];
+    p.deps_part[blockIdx.x] += sum;
+  }
+}
+
+// plans whose reverse pass stays layered but whose dense trunk has a single-call kernel: the 8x8 ConvNet3D trunk
+int trunk_bwd_supported(const l2hmc_dense_net* n) {
+  return n->D == 128 && n->H == 256 && n->Ka + n->Kb == 128;
+}
+
+int launch_trunk_bwd_pack(const l2hmc_dense_net* n, float* pack, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_fused_bwd_kernel, dim3(256), dim3(256), 0, stream, *n, pack);
+  L2HMC_CHECK_LAUNCH("pack_fused_bwd");
+  return L2HMC_OK;
+}
+
+int launch_trunk_bwd(TrunkBwdArgs& a, hipStream_t stream) {
+  using Cfg = TrunkBwdCfg<128, 256, 128>;
+  static DeviceOnce attr_once;
+  const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+  if (attr_once.pending()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_trunk_bwd_kernel<128, 256, 128>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("trunk backward: cannot reserve %zu B of LDS", lds);
+      return L2HMC_ERR_HIP;
+    }
+    attr_once.done();
+  }
+  hipLaunchKernelGGL((gauge_trunk_bwd_kernel<128, 256, 128>), dim3((unsigned)ceil_div(a.rows, kFM)), dim3(kFThreads),
+                     lds, stream, a);
+  L2HMC_CHECK_LAUNCH("gauge_trunk_bwd");
+  return L2HMC_OK;
+}
+
 size_t fused_bwd_pack_floats(const l2hmc_dense_net* n) {
   return (size_t)3 * n->D * n->H + (size_t)n->H * n->H + (size_t)n->H * (n->Ka + n->Kb);
 }

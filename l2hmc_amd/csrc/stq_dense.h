@@ -140,6 +140,26 @@ int launch_fused_train_backward(const l2hmc_gauge_plan* p, float beta, const int
                                 float* dv, const float* dld, const FusedTape& tx, const FusedTape& tv,
                                 float* const deltas_x[3], float* const deltas_v[3], float* pack_x, float* pack_v,
                                 float* const coef_parts[4], float* deps_part, hipStream_t stream);
+// one network call of a layered reverse pass in one launch (fused_train.hip: gauge_trunk_bwd_kernel)
+struct TrunkBwdArgs {
+  int mode;                                      // 1: momentum update (VNet call), 2: position update (XNet call)
+  float eps;
+  const float* pk;                               // backward image of the net (pack_fused_bwd_kernel)
+  const float* cs; const float* cq; int q_tanh;
+  const float* keep_f; const float* keep_b;      // mode 2: keep masks of this sub-update per direction
+  const int* dir; int64_t rows;
+  const float* stq; int64_t plane;               // this call's tape: S, T, Q planes; consumed state; raw inputs; h1; h2
+  const float* st; const float* in; const float* h1; const float* h2;
+  const float* dld;
+  float* dx; float* dv;                          // [rows][D] in/out
+  float* dg;                                     // mode 1 out: d loss / d force [rows][D]
+  float* dout; float* d2; float* d1;             // this call's delta tapes
+  float* dfeat;                                  // out [rows][K1]
+  float* dcs_part; float* dcq_part; float* deps_part;   // [workgroups][D] x 2, [workgroups]; +=
+};
+int trunk_bwd_supported(const l2hmc_dense_net* n);
+int launch_trunk_bwd_pack(const l2hmc_dense_net* n, float* pack, hipStream_t stream);
+int launch_trunk_bwd(TrunkBwdArgs& a, hipStream_t stream);
 int launch_u1_action_force(const float* x, int64_t rows, int T, int X, float beta, float* action,
                            float* force, float* avg_plaq, float* top_charge, hipStream_t stream);
 

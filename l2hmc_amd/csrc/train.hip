@@ -938,6 +938,9 @@ static int taped_call(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, con
 }
 
 // backward of one network call: heads' pre-activation gradients (in t.dout) -> t.d2, t.d1, w.din
+static int call_backward_conv(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, const NetTape& t, int call,
+                              int64_t rows, const TrainWs& w, hipStream_t s);
+
 static int call_backward_data(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, const NetTape& t, int call,
                               int64_t rows, const TrainWs& w, hipStream_t s) {
   const int D = net->D, H = net->H, Kin = net->Ka + net->Kb;
@@ -967,7 +970,14 @@ static int call_backward_data(const l2hmc_gauge_plan* p, const l2hmc_dense_net* 
   g0.out = conv ? w.dfeat : w.din; g0.ldo = Kin; g0.rows = rows;
   if (int e = launch_gemm_relu(g0, s)) return e;
   if (!conv) return L2HMC_OK;
-  // through the conv front-end to the raw inputs (w.din) and the filters (t.conv_part)
+  return call_backward_conv(p, net, t, call, rows, w, s);
+}
+
+// d loss / d features (w.dfeat) through the conv front-end to the raw inputs (w.din) and the filters (t.conv_part)
+static int call_backward_conv(const l2hmc_gauge_plan* p, const l2hmc_dense_net* net, const NetTape& t, int call,
+                              int64_t rows, const TrainWs& w, hipStream_t s) {
+  const int D = net->D, Kin = net->Ka + net->Kb;
+  const size_t cr = (size_t)call * rows;
   const l2hmc_conv3d_front* f = (net == &p->xnet) ? &p->xfront : &p->vfront;
   ConvBwdArgs b{};
   b.T = p->T; b.X = p->X; b.F = f->F;
@@ -1149,7 +1159,10 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
     }
   }
   const bool fused_bwd = fused_train_supported(plan);     // the forward call took the same branch and left the relu masks
-  if (!fused_bwd) {
+  // ConvNet3D plans with a single-call trunk kernel: element-wise phase + the three backward-data products of a call
+  // in ONE launch (fused_train.hip) instead of four
+  const bool trunk = !fused_bwd && conv && trunk_bwd_supported(&plan->xnet) && trunk_bwd_supported(&plan->vnet);
+  if (!fused_bwd && !trunk) {
     // weights as the layered backward-data products read them (k = output unit contiguous), once per pass
     // (the fused reverse pass packs its own fragment-ordered images instead)
     const l2hmc_dense_net* nets[2] = {&plan->xnet, &plan->vnet};
@@ -1174,9 +1187,28 @@ static int train_backward_impl(const l2hmc_gauge_plan* plan, float beta, const i
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vnet_in_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
   const int ublock = (int)hmin(256, (int64_t)align_up((size_t)D, 64));
+  if (trunk) {
+    if (int e = launch_trunk_bwd_pack(&plan->xnet, w.x.bpack, s)) return e;
+    if (int e = launch_trunk_bwd_pack(&plan->vnet, w.v.bpack, s)) return e;
+  }
   auto upd = [&](const l2hmc_dense_net* net, const NetTape& t, int call, int mode, const float* kf,
                  const float* kb) -> int {
     const size_t cr = (size_t)call * rows;
+    if (trunk) {
+      const int H = net->H;
+      TrunkBwdArgs a{};
+      a.mode = mode; a.eps = plan->eps; a.pk = t.bpack;
+      a.cs = net->coeff_s; a.cq = net->coeff_q; a.q_tanh = net->q_tanh;
+      a.keep_f = kf; a.keep_b = kb; a.dir = dir; a.rows = rows;
+      a.stq = t.stq + cr * 3 * D; a.plane = (int64_t)rows * D;
+      a.st = t.st + cr * D; a.in = t.in + cr * 2 * D; a.h1 = t.h1 + cr * H; a.h2 = t.h2 + cr * H;
+      a.dld = dlogdet; a.dx = dx; a.dv = dv; a.dg = w.dg;
+      a.dout = t.dout + cr * 3 * D; a.d2 = t.d2 + cr * H; a.d1 = t.d1 + cr * H;
+      a.dfeat = w.dfeat;
+      a.dcs_part = t.dcs_part; a.dcq_part = t.dcq_part; a.deps_part = w.eps_part;
+      if (int e = launch_trunk_bwd(a, s)) return e;
+      return call_backward_conv(plan, net, t, call, rows, w, s);
+    }
     UpdBwdArgs a{};
     a.mode = mode; a.rows = rows; a.D = D; a.eps = plan->eps;
     a.stq = t.stq + cr * 3 * D; a.plane = (int64_t)rows * D;
