@@ -334,6 +334,20 @@ def main():
         tcd = (time.perf_counter() - tc0) / 20
         out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
                                         "chain_leapfrog_steps_per_s": BATCH * N_LF / tcd}
+        if not args.no_train:
+            try:                                   # its training step (taped K1c forward, layered reverse pass)
+                from l2hmc_amd.gauge_trainer import GaugeTrainer
+                ctr = GaugeTrainer(cdyn, lr_init=1e-4)
+                for _ in range(2):
+                    ctr.train_step(x, BETA)
+                torch.cuda.synchronize()
+                tq0 = time.perf_counter()
+                for _ in range(10):
+                    ctr.train_step(x, BETA)
+                torch.cuda.synchronize()
+                out["config"]["conv3D_arch"]["train_ms_per_step"] = 1e3 * (time.perf_counter() - tq0) / 10
+            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line
+                out["config"]["conv3D_arch"]["train_error"] = repr(e)
 
     # ---- secondary: BASELINE.json configs[1], the 2-D mixture of Gaussians (mog_model.py): 4096 chains per GPU,
     #      10 LF steps, `propose` = forward + backward trajectories of every chain in one launch + mix/accept.

@@ -598,7 +598,7 @@ size_t conv3d_bwd_part_floats(int F) { return (size_t)18 * F + F + (size_t)16 * 
 // filter loads, the barriers and the read-modify-write of the workgroup's gradient slot
 int conv3d_cpw(int T, int X, int F) {
   const int per_chain = (T / 2) * (X / 2) * F;
-  const int c = 512 / per_chain;
+  const int c = 512 / per_chain;      // (measured at the 8x8 / F = 8 shape: 256 cells 5.08 ms per training step, 512 5.02, 1024 5.37, 2048 6.47)
   return c < 1 ? 1 : (c > 16 ? 16 : c);
 }
 
