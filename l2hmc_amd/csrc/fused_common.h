@@ -19,6 +19,21 @@ constexpr int kTPC = kFThreads / kFM;     // threads per chain in the chain-loca
 
 // (fast_exp / fast_tanh: common.h)
 
+// Tape traffic of the training kernels (1.2 GB written per forward pass, read once by the reverse pass and the
+// weight-gradient products, always from HBM): non-temporal, so that it does not push the weight images -- which
+// every workgroup re-reads from L2 at every network call -- out of the 4 MB L2 of its XCD.
+#ifdef L2HMC_TAPE_TEMPORAL      // diagnostic build only: default cache policy, to price the non-temporal one
+__device__ __forceinline__ void tape_store(float* dst, const f32x4& v) { *reinterpret_cast<f32x4*>(dst) = v; }
+__device__ __forceinline__ f32x4 tape_load(const float* src) { return *reinterpret_cast<const f32x4*>(src); }
+#else
+__device__ __forceinline__ void tape_store(float* dst, const f32x4& v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+}
+__device__ __forceinline__ f32x4 tape_load(const float* src) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // streaming GEMM core: acc[t] += A(16 x 16*NKC) . Wpacked, one wave, NT tiles
 // ---------------------------------------------------------------------------

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
     for (int i = tid; i < kFM * (W / 4); i += kFThreads) {
       const int rr = i / (W / 4), c4 = (i - rr * (W / 4)) * 4;
       if (rr < nrow)
-        *reinterpret_cast<f32x4*>(dst + (first_row + rr) * W + c4) = *reinterpret_cast<const f32x4*>(src + rr * stride + c4);
+        tape_store(dst + (first_row + rr) * W + c4, *reinterpret_cast<const f32x4*>(src + rr * stride + c4));
     }
   };
 
@@ -160,12 +160,12 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       t.vS[h] = t.vT[h] = t.vQ[h] = t.vst[h] = t.va[h] = t.vb[h] = z;
       if (live) {
         const float* sq = tp_.stq + (size_t)cidx_ * 3 * plane + ((size_t)row0 + fc) * D + c0 + 4 * h;
-        t.vS[h] = *reinterpret_cast<const f32x4*>(sq);
-        t.vT[h] = *reinterpret_cast<const f32x4*>(sq + plane);
-        t.vQ[h] = *reinterpret_cast<const f32x4*>(sq + 2 * plane);
-        t.vst[h] = *reinterpret_cast<const f32x4*>(tp_.st + (tcr + fc) * D + c0 + 4 * h);
-        t.va[h] = *reinterpret_cast<const f32x4*>(tp_.in + (tcr + fc) * (2 * D) + c0 + 4 * h);
-        t.vb[h] = *reinterpret_cast<const f32x4*>(tp_.in + (tcr + fc) * (2 * D) + D + c0 + 4 * h);
+        t.vS[h] = tape_load(sq);
+        t.vT[h] = tape_load(sq + plane);
+        t.vQ[h] = tape_load(sq + 2 * plane);
+        t.vst[h] = tape_load(tp_.st + (tcr + fc) * D + c0 + 4 * h);
+        t.va[h] = tape_load(tp_.in + (tcr + fc) * (2 * D) + c0 + 4 * h);
+        t.vb[h] = tape_load(tp_.in + (tcr + fc) * (2 * D) + D + c0 + 4 * h);
       }
     }
   };
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           *reinterpret_cast<f32x4*>(lo + 2 * D) = vq_;
           if (live) {
             float* go = dout_t + (tcr0 + fc) * (3 * D) + c0 + 4 * h;
-            *reinterpret_cast<f32x4*>(go) = vs_;
-            *reinterpret_cast<f32x4*>(go + D) = vt_;
-            *reinterpret_cast<f32x4*>(go + 2 * D) = vq_;
+            tape_store(go, vs_);
+            tape_store(go + D, vt_);
+            tape_store(go + 2 * D, vq_);
           }
         }
       }

@@ -481,10 +481,9 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           const int rr = i / (D / 4), c4 = (i - rr * (D / 4)) * 4;
           if (rr < nrow) {
             float* dst = tp.in + (tcr0 + rr) * (2 * D);
-            *reinterpret_cast<f32x4*>(dst + c4) = *reinterpret_cast<const f32x4*>(in1 + rr * SX + c4);
-            *reinterpret_cast<f32x4*>(dst + D + c4) = *reinterpret_cast<const f32x4*>(gs + rr * SX + c4);
-            *reinterpret_cast<f32x4*>(tp.st + (tcr0 + rr) * D + c4) =
-                *reinterpret_cast<const f32x4*>(stsrc + rr * SX + c4);
+            tape_store(dst + c4, *reinterpret_cast<const f32x4*>(in1 + rr * SX + c4));
+            tape_store(dst + D + c4, *reinterpret_cast<const f32x4*>(gs + rr * SX + c4));
+            tape_store(tp.st + (tcr0 + rr) * D + c4, *reinterpret_cast<const f32x4*>(stsrc + rr * SX + c4));
           }
         }
       }
@@ -493,7 +492,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       for (int i = tid; i < kFM * (H / 4); i += kFThreads) {
         const int rr = i / (H / 4), c4 = (i - rr * (H / 4)) * 4;
         if (rr < nrow)
-          *reinterpret_cast<f32x4*>(dst + (tcr0 + rr) * H + c4) = *reinterpret_cast<const f32x4*>(src + rr * SH + c4);
+          tape_store(dst + (tcr0 + rr) * H + c4, *reinterpret_cast<const f32x4*>(src + rr * SH + c4));
       }
     };
     const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
@@ -524,8 +523,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           for (int i = tid; i < kFM * (2 * KA / 4); i += kFThreads) {
             const int rr = i / (2 * KA / 4), c4 = (i - rr * (2 * KA / 4)) * 4;
             if (rr < nrow)
-              *reinterpret_cast<f32x4*>(tp.feat + (tcr0 + rr) * (2 * KA) + c4) =
-                  *reinterpret_cast<const f32x4*>((c4 < KA ? fa + rr * SA + c4 : fb + rr * SA + (c4 - KA)));
+              tape_store(tp.feat + (tcr0 + rr) * (2 * KA) + c4,
+                         *reinterpret_cast<const f32x4*>((c4 < KA ? fa + rr * SA + c4 : fb + rr * SA + (c4 - KA))));
           }
         }
       }
@@ -659,9 +658,9 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           if (r < nrow) {
             const size_t plane = (size_t)p.rows * D;
             float* o = tp.stq + (size_t)callidx * 3 * plane + ((size_t)row0 + r) * D + c0;
-            *reinterpret_cast<f32x4*>(o) = S;
-            *reinterpret_cast<f32x4*>(o + plane) = Tt;
-            *reinterpret_cast<f32x4*>(o + 2 * plane) = Q;
+            tape_store(o, S);
+            tape_store(o + plane, Tt);
+            tape_store(o + 2 * plane, Q);
           }
         }
         if (mode == 1) {
