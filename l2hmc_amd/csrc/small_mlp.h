@@ -36,19 +36,19 @@ template <int HP>
 __device__ void load_net(const l2hmc_dense_net& n, float* L, int dim) {
   const SmallNetView v = small_net_view(HP, dim);
   const int H = n.H, tid = threadIdx.x;
-  for (int i = tid; i < v.size; i += kSmallThreads) L[i] = 0.f;
+  for (int i = tid; i < v.size; i += blockDim.x) L[i] = 0.f;
   __syncthreads();
   // packed global layouts: w1_t [H][2*dim], wh_t [H (out)][H (in)], whd_t [3][dim][H]
-  for (int i = tid; i < H * 2 * dim; i += kSmallThreads) L[v.w1 + (i % (2 * dim)) * HP + i / (2 * dim)] = n.w1_t[i];
-  for (int i = tid; i < 2 * H; i += kSmallThreads) L[v.wt + (i / H) * HP + (i % H)] = n.wt[i];
-  for (int i = tid; i < H; i += kSmallThreads) {
+  for (int i = tid; i < H * 2 * dim; i += blockDim.x) L[v.w1 + (i % (2 * dim)) * HP + i / (2 * dim)] = n.w1_t[i];
+  for (int i = tid; i < 2 * H; i += blockDim.x) L[v.wt + (i / H) * HP + (i % H)] = n.wt[i];
+  for (int i = tid; i < H; i += blockDim.x) {
     L[v.b1 + i] = n.b1[i];
     L[v.bh + i] = n.bh[i];
   }
-  for (int i = tid; i < H * H; i += kSmallThreads) L[v.wh + (i % H) * HP + i / H] = n.wh_t[i];
-  for (int i = tid; i < 3 * dim * H; i += kSmallThreads) L[v.whd + (i / H) * HP + (i % H)] = n.whd_t[i];
-  for (int i = tid; i < 3 * dim; i += kSmallThreads) L[v.bhd + i] = n.bhd[i];
-  for (int i = tid; i < dim; i += kSmallThreads) {
+  for (int i = tid; i < H * H; i += blockDim.x) L[v.wh + (i % H) * HP + i / H] = n.wh_t[i];
+  for (int i = tid; i < 3 * dim * H; i += blockDim.x) L[v.whd + (i / H) * HP + (i % H)] = n.whd_t[i];
+  for (int i = tid; i < 3 * dim; i += blockDim.x) L[v.bhd + i] = n.bhd[i];
+  for (int i = tid; i < dim; i += blockDim.x) {
     L[v.es + i] = expf(n.coeff_s[i]);
     L[v.eq + i] = expf(n.coeff_q[i]);
   }
@@ -106,12 +106,11 @@ __device__ void net_eval(const float* L, int dim, int q_tanh, const float* a, co
         pt += h2[j] * wt[j];
         pq += h2[j] * wq[j];
       }
-#pragma unroll
-      for (int off = kLPC / 2; off > 0; off >>= 1) {
-        ps += __shfl_xor(ps, off, 64);
-        pt += __shfl_xor(pt, off, 64);
-        pq += __shfl_xor(pq, off, 64);
-      }
+      // the chain's sixteen lanes are one DPP row: four VALU steps each instead of four ds_bpermute round trips
+      static_assert(kLPC == 16, "row16_sum reduces over the 16 lanes of a chain");
+      ps = row16_sum(ps);
+      pt = row16_sum(pt);
+      pq = row16_sum(pq);
       const float s = ps + L[v.bhd + d], t = pt + L[v.bhd + dim + d], q = pq + L[v.bhd + 2 * dim + d];
       S[d] = tanhf(s) * L[v.es + d];
       T[d] = t;
@@ -190,9 +189,9 @@ __device__ inline void energy_grad(const float* Lt, int dim, int K, int is_gauss
 
 __device__ inline void load_target(const l2hmc_mog_target& t, float* Lt) {
   const TargetView tv = target_view(t.dim, t.K);
-  for (int i = threadIdx.x; i < t.K * t.dim; i += kSmallThreads) Lt[tv.mu + i] = t.mu[i];
-  for (int i = threadIdx.x; i < t.K * t.dim * t.dim; i += kSmallThreads) Lt[tv.prec + i] = t.prec[i];
-  for (int i = threadIdx.x; i < t.K; i += kSmallThreads) Lt[tv.logc + i] = t.is_gaussian ? 0.f : t.log_const[i];
+  for (int i = threadIdx.x; i < t.K * t.dim; i += blockDim.x) Lt[tv.mu + i] = t.mu[i];
+  for (int i = threadIdx.x; i < t.K * t.dim * t.dim; i += blockDim.x) Lt[tv.prec + i] = t.prec[i];
+  for (int i = threadIdx.x; i < t.K; i += blockDim.x) Lt[tv.logc + i] = t.is_gaussian ? 0.f : t.log_const[i];
 }
 
 

@@ -21,24 +21,27 @@
 //    writes its partial gradient (same layout as the packed weights), summed in order afterwards.
 // No atomics anywhere: gradients are reproducible.
 #include "small_mlp.h"
+#include <type_traits>
+#include "stq_dense.h"      // diagnostic stamp globals
 
 namespace l2hmc {
 
-constexpr int kSlots = kSmallThreads / kLPC;   // chains per workgroup
+constexpr int kSlotsMin = kSmallThreads / kLPC;   // chains per workgroup of the 256-thread instance (sizes the workspace)
+// TH: threads per workgroup (256: 16 chains, one wave per SIMD; 512: 32 chains, two waves per SIMD)
 // per-slot LDS row: a, b (2 MD) | tc ts | dout (3 MD) | dSS dQQ (2 MD)
 constexpr int small_misc(int MD) { return 8 * MD + 8; }
 
-template <int HP, int MD>
+template <int HP, int MD, int TH>
 struct SmallAcc {   // per-thread weight-gradient accumulators of one network
   static constexpr int kMaxDim = MD;
-  float wh[HP * HP / kSmallThreads > 0 ? HP * HP / kSmallThreads : 1];
-  float w1[((2 * kMaxDim + 2) * HP + kSmallThreads - 1) / kSmallThreads];
-  float whd[(3 * kMaxDim * HP + kSmallThreads - 1) / kSmallThreads];
+  float wh[HP * HP / TH > 0 ? HP * HP / TH : 1];
+  float w1[((2 * kMaxDim + 2) * HP + TH - 1) / TH];
+  float whd[(3 * kMaxDim * HP + TH - 1) / TH];
   float b1, bh, bhd, cs, cq;
 };
 
-template <int HP, int MD>
-__device__ __forceinline__ void acc_zero(SmallAcc<HP, MD>& a) {
+template <int HP, int MD, int TH>
+__device__ __forceinline__ void acc_zero(SmallAcc<HP, MD, TH>& a) {
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(a.wh) / 4); ++i) a.wh[i] = 0.f;
 #pragma unroll
@@ -49,20 +52,38 @@ __device__ __forceinline__ void acc_zero(SmallAcc<HP, MD>& a) {
 }
 
 // one network call's contribution of the workgroup's sixteen chains, slot order
-template <int HP, int MD>
-__device__ __forceinline__ void acc_add(SmallAcc<HP, MD>& a, int dim, const float* Rh1, const float* Rh2,
+// Row buffers Rh1 / Rh2 / Rd1 / Rd2 are [unit][slot] (the 16 chains of a unit contiguous): an owner thread reads a
+// unit's sixteen values as four 16-byte LDS reads, and since entry e = tid + 256 i keeps its input unit k = tid % HP
+// for every i, the h1 column is read once per call for all of the thread's hidden-matrix entries (68 ds_read_b128
+// per call where the [slot][unit] layout took 512 scalar reads).  Sums run over the slots in order, as before.
+using f32x4t = __attribute__((ext_vector_type(4))) float;
+template <int SLOTS>
+__device__ __forceinline__ float dot16(const f32x4t (&a)[SLOTS / 4], const float* b16) {
+  float s = 0.f;
+#pragma unroll
+  for (int q4 = 0; q4 < SLOTS / 4; ++q4) {
+    const f32x4t b = *reinterpret_cast<const f32x4t*>(b16 + 4 * q4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += a[q4][e] * b[e];
+  }
+  return s;
+}
+template <int HP, int MD, int TH>
+__device__ __forceinline__ void acc_add(SmallAcc<HP, MD, TH>& a, int dim, const float* Rh1, const float* Rh2,
                                         const float* Rd1, const float* Rd2, const float* Rm) {
-  constexpr int kMaxDim = MD, kMisc = small_misc(MD);
+  constexpr int kMaxDim = MD, kSlots = TH / kLPC, kSmallThreads = TH;
+  constexpr int SS = kSlots + 4;          // padded row stride: units 4 banks apart modulo 64, 16-byte rows
+  static_assert(kSlots % 4 == 0 && kSmallThreads % HP == 0, "slot vectors / fixed input unit per owner thread");
   const int tid = threadIdx.x;
+  {
+    const int k = tid % HP;                                   // the same for every entry of this thread
+    f32x4t hk[kSlots / 4];
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(a.wh) / 4); ++i) {
-    const int e = tid + i * kSmallThreads;
-    if (e < HP * HP) {
-      const int n = e / HP, k = e - n * HP;
-      float s = 0.f;
+    for (int q4 = 0; q4 < kSlots / 4; ++q4) hk[q4] = *reinterpret_cast<const f32x4t*>(Rh1 + k * SS + 4 * q4);
 #pragma unroll
-      for (int sl = 0; sl < kSlots; ++sl) s += Rh1[sl * HP + k] * Rd2[sl * HP + n];
-      a.wh[i] += s;
+    for (int i = 0; i < (int)(sizeof(a.wh) / 4); ++i) {
+      const int e = tid + i * kSmallThreads;
+      if (e < HP * HP) a.wh[i] += dot16<kSlots>(hk, Rd2 + (e / HP) * SS);
     }
   }
 #pragma unroll
@@ -71,10 +92,10 @@ __device__ __forceinline__ void acc_add(SmallAcc<HP, MD>& a, int dim, const floa
     if (e < (2 * dim + 2) * HP) {
       const int kin = e / HP, n = e - kin * HP;     // rows: a (dim), b (dim), cos, sin
       const int src = kin < 2 * dim ? kin : 2 * kMaxDim + (kin - 2 * dim);
-      float s = 0.f;
+      f32x4t mv[kSlots / 4];
 #pragma unroll
-      for (int sl = 0; sl < kSlots; ++sl) s += Rm[sl * kMisc + src] * Rd1[sl * HP + n];
-      a.w1[i] += s;
+      for (int q4 = 0; q4 < kSlots / 4; ++q4) mv[q4] = *reinterpret_cast<const f32x4t*>(Rm + src * SS + 4 * q4);
+      a.w1[i] += dot16<kSlots>(mv, Rd1 + n * SS);
     }
   }
 #pragma unroll
@@ -83,18 +104,18 @@ __device__ __forceinline__ void acc_add(SmallAcc<HP, MD>& a, int dim, const floa
     if (e < 3 * dim * HP) {
       const int hd = e / HP, n = e - hd * HP;       // hd = head * dim + d
       const int src = 2 * kMaxDim + 2 + (hd / dim) * kMaxDim + hd % dim;
-      float s = 0.f;
+      f32x4t mv[kSlots / 4];
 #pragma unroll
-      for (int sl = 0; sl < kSlots; ++sl) s += Rm[sl * kMisc + src] * Rh2[sl * HP + n];
-      a.whd[i] += s;
+      for (int q4 = 0; q4 < kSlots / 4; ++q4) mv[q4] = *reinterpret_cast<const f32x4t*>(Rm + src * SS + 4 * q4);
+      a.whd[i] += dot16<kSlots>(mv, Rh2 + n * SS);
     }
   }
   if (tid < HP) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int sl = 0; sl < kSlots; ++sl) {
-      s1 += Rd1[sl * HP + tid];
-      s2 += Rd2[sl * HP + tid];
+      s1 += Rd1[tid * SS + sl];
+      s2 += Rd2[tid * SS + sl];
     }
     a.b1 += s1;
     a.bh += s2;
@@ -103,15 +124,15 @@ __device__ __forceinline__ void acc_add(SmallAcc<HP, MD>& a, int dim, const floa
     const int src = 2 * kMaxDim + 2 + (tid / dim) * kMaxDim + tid % dim;
     float s = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < kSlots; ++sl) s += Rm[sl * kMisc + src];
+    for (int sl = 0; sl < kSlots; ++sl) s += Rm[src * SS + sl];
     a.bhd += s;
   }
   if (tid < dim) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int sl = 0; sl < kSlots; ++sl) {
-      s1 += Rm[sl * kMisc + 5 * kMaxDim + 2 + tid];
-      s2 += Rm[sl * kMisc + 6 * kMaxDim + 2 + tid];
+      s1 += Rm[(5 * kMaxDim + 2 + tid) * SS + sl];
+      s2 += Rm[(6 * kMaxDim + 2 + tid) * SS + sl];
     }
     a.cs += s1;
     a.cq += s2;
@@ -124,9 +145,9 @@ __host__ __device__ inline int small_grad_floats(int H, int dim) {
   return H * 2 * dim + 2 * H + H + H * H + H + 3 * dim * H + 3 * dim + 2 * dim;
 }
 
-template <int HP, int MD>
-__device__ __forceinline__ void acc_store(const SmallAcc<HP, MD>& a, int H, int dim, float* out) {
-  constexpr int kMaxDim = MD;
+template <int HP, int MD, int TH>
+__device__ __forceinline__ void acc_store(const SmallAcc<HP, MD, TH>& a, int H, int dim, float* out) {
+  constexpr int kMaxDim = MD, kSmallThreads = TH;
   (void)kMaxDim;
   const int tid = threadIdx.x;
   float* w1 = out;
@@ -224,12 +245,11 @@ __device__ void net_eval_keep(const float* L, int dim, int q_tanh, const float* 
         pt += h2[j] * wt[j];
         pq += h2[j] * wq[j];
       }
-#pragma unroll
-      for (int off = kLPC / 2; off > 0; off >>= 1) {
-        ps += __shfl_xor(ps, off, 64);
-        pt += __shfl_xor(pt, off, 64);
-        pq += __shfl_xor(pq, off, 64);
-      }
+      // the chain's sixteen lanes are one DPP row: four VALU steps each instead of four ds_bpermute round trips
+      static_assert(kLPC == 16, "row16_sum reduces over the 16 lanes of a chain");
+      ps = row16_sum(ps);
+      pt = row16_sum(pt);
+      pq = row16_sum(pq);
       const float s = ps + L[v.bhd + d], t = pt + L[v.bhd + dim + d], q = pq + L[v.bhd + 2 * dim + d];
       S[d] = tanhf(s) * L[v.es + d];
       T[d] = t;
@@ -317,13 +337,34 @@ struct SmallTrainArgs {
   float scale, inv_count;
   float* x_out; float* v_out; float* p_accept; float* terms;
   float* part;        // [workgroups][2 * gsize + 1]: xnet gradient | vnet gradient | d loss / d eps
+  unsigned long long* stamps;      // diagnostic builds only
 };
 
-template <int HP, int MD>
-__global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainArgs a) {
+#ifdef L2HMC_STAMPS
+#define ST_NOW()                                                                              \
+  ({                                                                                          \
+    unsigned long long t_;                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    t_;                                                                                       \
+  })
+#define ST_ADD(slot, t0) st_[slot] += ST_NOW() - (t0)
+#else
+#define ST_NOW() 0ull
+#define ST_ADD(slot, t0) do {} while (0)
+#endif
+
+template <int HP, int MD, int TH>
+__global__ __launch_bounds__(TH) void small_train_kernel(SmallTrainArgs a) {
+  constexpr int kSlots = TH / kLPC, kSmallThreads = TH, SS = kSlots + 4;
+  // diagnostic cycle shares (class 7): 0 prologue, 1 forward, 2 loss, 3 net re-evaluation, 4 sub-update + head deltas,
+  // 5 hidden deltas (d2, d1, input gradients), 6 owner pass, 7 total
+  [[maybe_unused]] unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] const unsigned long long st_begin = ST_NOW();
   constexpr int kMaxDim = MD, kMisc = small_misc(MD);      // shadow the library-wide bound for this instance
   constexpr int UPL = HP / kLPC;
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // (every carve-out below is a multiple of 16 bytes)
   const l2hmc_small_plan& P = a.plan;
   const int dim = P.x_dim, N = P.trajectory_length, H = P.num_nodes;
   const int ncalls = 4 * N;
@@ -336,12 +377,12 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   float* Lt = LvT + HP * HP;
   float* Lm = Lt + tv.size;                        // masks [N][dim]
   float* hx = Lm + ((N * dim + 3) & ~3);           // [16][HP] forward hidden-vector exchange
-  float* Rh1 = hx + kSlots * HP;                   // backward rows [16][HP]
-  float* Rh2 = Rh1 + kSlots * HP;
-  float* Rd1 = Rh2 + kSlots * HP;
-  float* Rd2 = Rd1 + kSlots * HP;
-  float* Rm = Rd2 + kSlots * HP;                   // [16][kMisc]
-  float* tape = Rm + kSlots * kMisc;               // [16][ncalls][3 * dim]: a, b, updated state
+  float* Rh1 = hx + kSlots * HP;                   // backward rows [HP][slots + 4 pad]
+  float* Rh2 = Rh1 + SS * HP;
+  float* Rd1 = Rh2 + SS * HP;
+  float* Rd2 = Rd1 + SS * HP;
+  float* Rm = Rd2 + SS * HP;                       // [kMisc][slots + 4 pad]
+  float* tape = Rm + SS * kMisc;               // [16][ncalls][3 * dim]: a, b, updated state
   load_net<HP>(P.xnet, Lx, dim);
   load_net<HP>(P.vnet, Lv, dim);
   for (int i = threadIdx.x; i < HP * HP; i += kSmallThreads) {
@@ -378,6 +419,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   for (int d = 0; d < kMaxDim; ++d) kin0 += v[d] * v[d];
   const float H0 = E0 + 0.5f * kin0;
 
+  ST_ADD(0, st_begin);
+  [[maybe_unused]] unsigned long long st_t = ST_NOW();
   // ------------------------------------------------------------------ forward, taping call inputs
   float logdet = 0.f;
   float S[kMaxDim], T[kMaxDim], Q[kMaxDim], bin[kMaxDim], h1[UPL], h2[UPL];
@@ -445,6 +488,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   const float H1 = E1 + 0.5f * kin1;
   const float p = accept_from_delta(H0 - H1 + logdet);
 
+  ST_ADD(1, st_t);
+  st_t = ST_NOW();
   // ------------------------------------------------------------------ loss (mog_model.py:336-355)
   float dist2 = 0.f;
 #pragma unroll
@@ -474,8 +519,9 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   const float dl = dD;
   float deps = 0.f;
 
+  ST_ADD(2, st_t);
   // ------------------------------------------------------------------ reverse pass
-  SmallAcc<HP, MD> accX, accV;
+  SmallAcc<HP, MD, TH> accX, accV;
   acc_zero(accX);
   acc_zero(accV);
   for (int c = ncalls - 1; c >= 0; --c) {
@@ -496,7 +542,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
       bin[d] = d < dim ? tp[dim + d] : 0.f;
       st[d] = d < dim ? tp[2 * dim + d] : 0.f;
     }
+    st_t = ST_NOW();
     net_eval_keep<HP, MD>(L, dim, q_tanh, ain, bin, tc, ts, lsub, hrow, h1, h2, S, T, Q);
+    ST_ADD(3, st_t);
+    st_t = ST_NOW();
     const SmallNetView nvw = small_net_view(HP, dim);
     // ---- sub-update backward -> head pre-activation gradients (replicated over the chain's lanes)
     float dS[kMaxDim], dT[kMaxDim], dQ[kMaxDim], dgd[kMaxDim], keep[kMaxDim];
@@ -568,6 +617,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
       dSS[d] = dS[d] * S[d];
       dQQ[d] = dQ[d] * Q[d];
     }
+    ST_ADD(4, st_t);
+    st_t = ST_NOW();
     // ---- hidden deltas
     float d2[UPL], d1[UPL];
 #pragma unroll
@@ -583,15 +634,15 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
     __syncthreads();                               // previous call's owner pass has finished reading the rows
 #pragma unroll
     for (int j = 0; j < UPL; ++j) {
-      Rd2[slot * HP + n0 + j] = d2[j];
-      Rh2[slot * HP + n0 + j] = h2[j];
-      Rh1[slot * HP + n0 + j] = h1[j];
+      Rd2[(n0 + j) * SS + slot] = d2[j];
+      Rh2[(n0 + j) * SS + slot] = h2[j];
+      Rh1[(n0 + j) * SS + slot] = h1[j];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < UPL; ++j) d1[j] = 0.f;
     for (int n = 0; n < HP; ++n) {
-      const float dn = Rd2[slot * HP + n];
+      const float dn = Rd2[n * SS + slot];
       const float* w = LT + n * HP + n0;            // [n][k]: this lane's input units are contiguous
 #pragma unroll
       for (int j = 0; j < UPL; ++j) d1[j] += dn * w[j];
@@ -599,7 +650,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
 #pragma unroll
     for (int j = 0; j < UPL; ++j) {
       d1[j] = h1[j] > 0.f ? d1[j] : 0.f;
-      Rd1[slot * HP + n0 + j] = d1[j];
+      Rd1[(n0 + j) * SS + slot] = d1[j];
     }
     // ---- gradient with respect to the two network inputs: k-split over the lanes + butterfly
     float da[kMaxDim], db[kMaxDim];
@@ -613,34 +664,34 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
         pa += d1[j] * L[nvw.w1 + d * HP + n0 + j];
         pb += d1[j] * L[nvw.w1 + (dim + d) * HP + n0 + j];
       }
-#pragma unroll
-      for (int off = kLPC / 2; off > 0; off >>= 1) {
-        pa += __shfl_xor(pa, off, 64);
-        pb += __shfl_xor(pb, off, 64);
-      }
+      pa = row16_sum(pa);
+      pb = row16_sum(pb);
       da[d] = pa;
       db[d] = pb;
     }
     if (lsub == 0) {
-      float* rm = Rm + slot * kMisc;        // first-layer input rows compact: a at [0, dim), b at [dim, 2 dim)
+      float* rm = Rm + slot;                // [kMisc][slots + 4 pad]; first-layer input rows compact: a at [0, dim), b at [dim, 2 dim)
 #pragma unroll
       for (int d = 0; d < kMaxDim; ++d) {
         if (d < dim) {
-          rm[d] = ain[d];
-          rm[dim + d] = bin[d];
+          rm[d * SS] = ain[d];
+          rm[(dim + d) * SS] = bin[d];
         }
-        rm[2 * kMaxDim + 2 + d] = dout[0][d];
-        rm[3 * kMaxDim + 2 + d] = dout[1][d];
-        rm[4 * kMaxDim + 2 + d] = dout[2][d];
-        rm[5 * kMaxDim + 2 + d] = dSS[d];
-        rm[6 * kMaxDim + 2 + d] = dQQ[d];
+        rm[(2 * kMaxDim + 2 + d) * SS] = dout[0][d];
+        rm[(3 * kMaxDim + 2 + d) * SS] = dout[1][d];
+        rm[(4 * kMaxDim + 2 + d) * SS] = dout[2][d];
+        rm[(5 * kMaxDim + 2 + d) * SS] = dSS[d];
+        rm[(6 * kMaxDim + 2 + d) * SS] = dQQ[d];
       }
-      rm[2 * kMaxDim] = live ? tc : 0.f;
-      rm[2 * kMaxDim + 1] = live ? ts : 0.f;
+      rm[(2 * kMaxDim) * SS] = live ? tc : 0.f;
+      rm[(2 * kMaxDim + 1) * SS] = live ? ts : 0.f;
     }
     __syncthreads();
-    if (vcall) acc_add<HP, MD>(accV, dim, Rh1, Rh2, Rd1, Rd2, Rm);
-    else acc_add<HP, MD>(accX, dim, Rh1, Rh2, Rd1, Rd2, Rm);
+    ST_ADD(5, st_t);
+    st_t = ST_NOW();
+    if (vcall) acc_add<HP, MD, TH>(accV, dim, Rh1, Rh2, Rd1, Rd2, Rm);
+    else acc_add<HP, MD, TH>(accX, dim, Rh1, Rh2, Rd1, Rd2, Rm);
+    ST_ADD(6, st_t);
     // ---- into the upstream gradients
     if (vcall) {
       float u[kMaxDim], hv[kMaxDim];
@@ -660,16 +711,22 @@ __global__ __launch_bounds__(kSmallThreads) void small_train_kernel(SmallTrainAr
   // ------------------------------------------------------------------ partial gradients of this workgroup
   const int gsize = small_grad_floats(H, dim);
   float* out = a.part + (size_t)blockIdx.x * (2 * gsize + 1);
-  acc_store<HP, MD>(accX, H, dim, out);
-  acc_store<HP, MD>(accV, H, dim, out + gsize);
+  acc_store<HP, MD, TH>(accX, H, dim, out);
+  acc_store<HP, MD, TH>(accV, H, dim, out + gsize);
   __syncthreads();
-  if (lsub == 0) Rm[slot * kMisc] = live ? deps : 0.f;
+  if (lsub == 0) Rm[slot] = live ? deps : 0.f;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int sl = 0; sl < kSlots; ++sl) s += Rm[sl * kMisc];
+    for (int sl = 0; sl < kSlots; ++sl) s += Rm[sl];
     out[2 * gsize] = s;
   }
+#ifdef L2HMC_STAMPS
+  if (a.stamps && threadIdx.x == 0) {
+    st_[7] = ST_NOW() - st_begin;
+    for (int i = 0; i < 8; ++i) a.stamps[blockIdx.x * 8 + i] = st_[i];
+  }
+#endif
 }
 
 __global__ __launch_bounds__(256) void small_reduce_kernel(const float* __restrict__ part, int S, int64_t count,
@@ -685,11 +742,11 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(const float* __restri
   if (sl == 0 && i < count) out[i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
-template <int HP, int MD>
+template <int HP, int MD, int TH>
 static size_t small_train_lds(int dim, int K, int N) {
-  constexpr int kMisc = small_misc(MD);
+  constexpr int kMisc = small_misc(MD), kSlots = TH / kLPC;
   return sizeof(float) * (2 * (size_t)small_net_view(HP, dim).size + 2 * (size_t)HP * HP + target_view(dim, K).size +
-                          ((N * dim + 3) & ~3) + 5 * (size_t)kSlots * HP + (size_t)kSlots * kMisc +
+                          ((N * dim + 3) & ~3) + (size_t)kSlots * HP + 4 * (size_t)(kSlots + 4) * HP + (size_t)(kSlots + 4) * kMisc +
                           (size_t)kSlots * 4 * N * 3 * dim);
 }
 
@@ -700,7 +757,7 @@ using namespace l2hmc;
 extern "C" size_t l2hmc_small_train_ws_bytes(const l2hmc_small_plan* plan, int64_t rows) {
   if (!plan || rows <= 0 || plan->hmc) return 0;
   const size_t g = small_grad_floats(plan->num_nodes, plan->x_dim);
-  return sizeof(float) * (size_t)ceil_div(rows, kSlots) * (2 * g + 1);
+  return sizeof(float) * (size_t)ceil_div(rows, kSlotsMin) * (2 * g + 1);
 }
 
 extern "C" int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float* x0, const float* v0,
@@ -731,33 +788,37 @@ extern "C" int l2hmc_small_train_step(const l2hmc_small_plan* plan, const float*
   }
   const int HP = H <= 16 ? 16 : 64;
   const bool d2 = dim <= 2;          // x_dim 2 instance for the benchmark targets
-  const size_t lds = d2 ? (HP == 16 ? small_train_lds<16, 2>(dim, plan->target.K, N) : small_train_lds<64, 2>(dim, plan->target.K, N))
-                        : (HP == 16 ? small_train_lds<16, kMaxDim>(dim, plan->target.K, N)
-                                    : small_train_lds<64, kMaxDim>(dim, plan->target.K, N));
-  L2HMC_REQUIRE(lds <= 160 * 1024, "small_train_step: LDS image %zu B too large (trajectory too long?)", lds);
-  static DeviceOnce attr_once;
-  if (attr_once.pending()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<16, kMaxDim>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<64, kMaxDim>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_once.done();
-  }
   hipStream_t s = (hipStream_t)stream;
-  const int nwg = (int)ceil_div(rows, kSlots);
-  SmallTrainArgs a{*plan, x0, v0, dir, rows, scale, inv_count, x_out, v_out, p_accept, terms, static_cast<float*>(ws)};
-  const dim3 blk(kSmallThreads);
-  if (d2) {
-    if (HP == 16) hipLaunchKernelGGL((small_train_kernel<16, 2>), dim3(nwg), blk, lds, s, a);
-    else hipLaunchKernelGGL((small_train_kernel<64, 2>), dim3(nwg), blk, lds, s, a);
-  } else {
-    if (HP == 16) hipLaunchKernelGGL((small_train_kernel<16, kMaxDim>), dim3(nwg), blk, lds, s, a);
-    else hipLaunchKernelGGL((small_train_kernel<64, kMaxDim>), dim3(nwg), blk, lds, s, a);
-  }
+  int nwg = 0;
+  // (TH = 512 -- 32 chains, two waves per SIMD, one round of workgroups for 8192 chains -- was measured: 1.59 ms per
+  //  step against 1.46 for two rounds of 16-chain workgroups: the kernel is bound by LDS throughput, not latency)
+  auto run = [&](auto hp, auto md) -> int {
+    constexpr int HPc = decltype(hp)::value, MDc = decltype(md)::value;
+    const size_t lds = small_train_lds<HPc, MDc, 256>(dim, plan->target.K, N);
+    L2HMC_REQUIRE(lds <= 160 * 1024, "small_train_step: LDS image %zu B too large (trajectory too long?)", lds);
+    static DeviceOnce attr_once;
+    if (attr_once.pending()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_train_kernel<HPc, MDc, 256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_once.done();
+    }
+    SmallTrainArgs a{*plan, x0, v0, dir, rows, scale, inv_count, x_out, v_out, p_accept, terms, static_cast<float*>(ws),
+                     nullptr};
+#ifdef L2HMC_STAMPS
+    a.stamps = g_stamp_cls == 7 ? g_stamp_buf : nullptr;
+#endif
+    nwg = (int)ceil_div(rows, 256 / kLPC);
+    hipLaunchKernelGGL((small_train_kernel<HPc, MDc, 256>), dim3(nwg), dim3(256), lds, s, a);
+    return L2HMC_OK;
+  };
+  using I16 = std::integral_constant<int, 16>;
+  using I64 = std::integral_constant<int, 64>;
+  using I2 = std::integral_constant<int, 2>;
+  using IM = std::integral_constant<int, kMaxDim>;
+  int rc;
+  if (d2) rc = HP == 16 ? run(I16{}, I2{}) : run(I64{}, I2{});
+  else rc = HP == 16 ? run(I16{}, IM{}) : run(I64{}, IM{});
+  if (rc) return rc;
   L2HMC_CHECK_LAUNCH("small_train");
   const int64_t count = 2 * (int64_t)small_grad_floats(H, dim) + 1;
   hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)ceil_div(count, 64)), dim3(256), 0, s,

@@ -6,9 +6,10 @@ for NW in ${DIAG_WAVES_LIST:-4}; do
   OUT=../../tools/_diag/w$NW
   mkdir -p $OUT
   for f in capi u1_lattice stq_dense leapfrog small_mlp fused_traj conv3d_front mcmc_step loss train small_train fused_train; do
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DL2HMC_STAMPS -DL2HMC_FUSED_WAVES=$NW $EXTRA -c $f.hip -o $OUT/$f.o &
+    ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DL2HMC_STAMPS -DL2HMC_FUSED_WAVES=$NW $EXTRA -c $f.hip -o $OUT/$f.o || touch $OUT/FAILED ) &
   done
   wait
+  if [ -e $OUT/FAILED ]; then rm -f $OUT/FAILED; echo "diagnostic build FAILED (see the compiler output above)"; exit 1; fi
   hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -o ../../tools/_diag/libl2hmc_hip_diag_w$NW.so
 done
 cp ../../tools/_diag/libl2hmc_hip_diag_w4.so ../../tools/_diag/libl2hmc_hip_diag.so
