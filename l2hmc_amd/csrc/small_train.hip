@@ -224,11 +224,20 @@ __device__ void net_eval_keep(const float* L, int dim, int q_tanh, const float* 
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < UPL; ++j) h2[j] = L[v.bh + n0 + j];
-  for (int k = 0; k < HP; ++k) {
-    const float hk = hrow[k];
+  // four input units per step: one 16-byte read of the hidden row (broadcast within the chain's 16 lanes) instead of
+  // four scalar ones -- the loop is LDS-issue-bound (one weight read per UPL multiply-adds); same summation order
+  using hvec4 = __attribute__((ext_vector_type(4))) float;
+#pragma unroll 4
+  for (int k = 0; k < HP; k += 4) {
+    const hvec4 hv = *reinterpret_cast<const hvec4*>(hrow + k);
     const float* w = L + v.wh + k * HP + n0;
 #pragma unroll
-    for (int j = 0; j < UPL; ++j) h2[j] += hk * w[j];
+    for (int j = 0; j < UPL; ++j) {
+      h2[j] += hv[0] * w[j];
+      h2[j] += hv[1] * w[HP + j];
+      h2[j] += hv[2] * w[2 * HP + j];
+      h2[j] += hv[3] * w[3 * HP + j];
+    }
   }
 #pragma unroll
   for (int j = 0; j < UPL; ++j) h2[j] = fmaxf(h2[j], 0.f);
