@@ -527,6 +527,41 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
   if (sl == 0 && i < n) outs.o[blockIdx.y][i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
+// Both reductions behind one weight-gradient product in ONE launch: blocks [0, nb1) sum the product's split-k partials
+// (as reduce_partials_kernel), the rest the column-sum planes (as reduce_planes_kernel: block (x, plane)).
+__global__ __launch_bounds__(256) void reduce_product_and_planes_kernel(const float* __restrict__ part, int S,
+                                                                        int64_t count, float* __restrict__ out,
+                                                                        int nb1, const float* __restrict__ cpart,
+                                                                        int cS, int n, PlaneOuts outs) {
+  __shared__ float red[4][64];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const bool first = (int)blockIdx.x < nb1;                     // uniform per block
+  float t = 0.f;
+  int64_t i;
+  float* dst;
+  if (first) {
+    i = (int64_t)blockIdx.x * 64 + il;
+    if (i < count) {
+#pragma unroll 8
+      for (int s = sl; s < S; s += 4) t += part[(size_t)s * count + i];
+    }
+    dst = (i < count) ? out + i : nullptr;
+  } else {
+    const int b = blockIdx.x - nb1, nbx = (n + 63) / 64;
+    const int plane = b / nbx;
+    i = (int64_t)(b - plane * nbx) * 64 + il;
+    const float* src = cpart + (size_t)plane * n;
+    if (i < n) {
+#pragma unroll 8
+      for (int s = sl; s < cS; s += 4) t += src[(size_t)s * 3 * n + i];
+    }
+    dst = (i < n) ? outs.o[plane] + i : nullptr;
+  }
+  red[sl][il] = t;
+  __syncthreads();
+  if (sl == 0 && dst) *dst = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+}
+
 // out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int Cn,
                                                         float* __restrict__ out) {
@@ -1032,10 +1067,18 @@ static int gemm_tn(const float* P, int M, const float* Q, int N, int64_t R, floa
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nprod + a.cs.ncg * a.cs.S), dim3(256), 0, s, a);
   L2HMC_CHECK_LAUNCH("gemm_tn");
   const int64_t count = (int64_t)M * N;
+  if (b_plain) {      // product partials and column-sum planes in one launch
+    const PlaneOuts outs{{b_plain, b_cos, b_sin}};
+    const int nb1 = (int)ceil_div(count, 64), nb2 = (int)ceil_div(M, 64) * (timed ? 3 : 1);
+    hipLaunchKernelGGL(reduce_product_and_planes_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, s, w.part, splits,
+                       count, out, nb1, a.cs.part, a.cs.S, M, outs);
+    L2HMC_CHECK_LAUNCH("reduce_product_and_planes");
+    return L2HMC_OK;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(count, 64)), dim3(256), 0, s, w.part, splits,
                      count, out);
   L2HMC_CHECK_LAUNCH("reduce_partials");
-  return b_plain ? colsum_finish(a.cs, b_plain, b_cos, b_sin, s) : L2HMC_OK;
+  return L2HMC_OK;
 }
 
 // stand-alone column sums (deltas whose weight gradient is not a TN product of this file)
