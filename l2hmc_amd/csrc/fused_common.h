@@ -66,34 +66,39 @@ struct BRing {
   f32x4 b[DEPTH][NT];
 };
 
+// rev: the layer's k-chunks are walked from the last to the first (NKC chunks in all).  A network's image is
+// streamed in alternating directions on its consecutive calls, so the part of it that the previous call left in L2
+// -- its most recently touched end -- is what the next call asks for first.
 template <int NT, int DEPTH>
-__device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp) {
+__device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp, bool rev = false,
+                                           int nkc = 0) {
 #pragma unroll
-  for (int s = 0; s < DEPTH; ++s) load_frags<NT>(R.b[s], wp, s);
+  for (int s = 0; s < DEPTH; ++s) load_frags<NT>(R.b[s], wp, rev ? nkc - 1 - s : s);
 }
 
 // wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
 // (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
 template <int NT, int NKC, int DEPTH, typename AF>
 __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wp, AF afrag,
-                                             f32x4 (&acc)[NT]) {
+                                             f32x4 (&acc)[NT], bool rev = false) {
   static_assert(NKC >= DEPTH, "ring depth");
-  f32x4 a0 = afrag(0);
+  auto km = [&](int k) { return rev ? NKC - 1 - k : k; };      // position in the walk -> chunk
+  f32x4 a0 = afrag(km(0));
   int kc = 0;
 #pragma nounroll
   for (; kc + DEPTH <= NKC; kc += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
-      const f32x4 a1 = afrag(kc + s + 1 < NKC ? kc + s + 1 : NKC - 1);
+      const f32x4 a1 = afrag(km(kc + s + 1 < NKC ? kc + s + 1 : NKC - 1));
       mfma_block<NT>(a0, R.b[s], acc);
-      if (kc + s + DEPTH < NKC) load_frags<NT>(R.b[s], wp, kc + s + DEPTH);
+      if (kc + s + DEPTH < NKC) load_frags<NT>(R.b[s], wp, km(kc + s + DEPTH));
       a0 = a1;
     }
   }
   constexpr int REM = NKC % DEPTH;        // their fragments were requested by the last full round
 #pragma unroll
   for (int s = 0; s < REM; ++s) {
-    const f32x4 a1 = afrag(NKC - REM + s + 1 < NKC ? NKC - REM + s + 1 : NKC - 1);
+    const f32x4 a1 = afrag(km(NKC - REM + s + 1 < NKC ? NKC - REM + s + 1 : NKC - 1));
     mfma_block<NT>(a0, R.b[s], acc);
     a0 = a1;
   }

@@ -471,6 +471,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
                         bool prep_next_mask, int l1, bool is_vnet, const float tcr, const float tsr,
                         int callidx) {
     const float* pk = net.packed;
+    // layers 2 and 3 of a network are streamed in alternating directions on its consecutive calls (fused_common.h)
+    const bool zig = (callidx & 1) != 0;
     // training tape (generic plans): this call's inputs and the state its sub-update consumes
     [[maybe_unused]] const FusedTape& tp = is_vnet ? p.tv : p.tx;
     [[maybe_unused]] const size_t tcr0 = (size_t)callidx * (size_t)p.rows + (size_t)row0;     // first taped row of this workgroup
@@ -558,7 +560,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           for (int t = 0; t < NT1; ++t) keep_v[t] = acc[t];
         }
       }
-      ring_prime<NT1, DP2>(R2, wp2);      // layer-2 weights start flowing under the epilogue + barrier
+      ring_prime<NT1, DP2>(R2, wp2, zig, Cfg::KC2);      // layer-2 weights start flowing under the epilogue + barrier
       FT_ADD(0, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -593,8 +595,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       const float* a = h1 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
       stream_layer<NT1, Cfg::KC2, DP2>(
-          R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
-      ring_prime<3 * NTH, DPH>(R3, wph);
+          R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig);
+      ring_prime<3 * NTH, DPH>(R3, wph, zig, Cfg::KC2);
       FT_ADD(1, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       const float* a = h2 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
       stream_layer<3 * NTH, Cfg::KC2, DPH>(
-          R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc);
+          R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig);
       FT_ADD(2, t0);
       t0 = FT_NOW();
       float ld = 0.f;                       // this lane's share of row r's log-det
