@@ -1,25 +1,31 @@
 #!/usr/bin/env python
 """Throughput of the L2HMC hot path on MI355X: chain-leapfrog-steps per second.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}] [--scaling {weak,strong}]
 
-One "step" is one `apply_transition` (dynamics/gauge_dynamics.py:195-259) over a
-batch of synthetic chains: momenta, direction coin and MH uniform drawn on the
-device, BOTH directions integrated (as the reference does), accept/reject,
-wrap to [0, 2pi) and per-step observables -- all resident in HBM.  Workload:
-BASELINE.json configs[2], the configuration its metric is quoted on (2D U(1)
-8x8, beta 2.0, batch 2048 per GPU, 10 leapfrog steps, GenericNet H=512, fp32).
+One "step" is one pass of the hot path over one batch of synthetic chains, everything resident in HBM:
+  * lattice configs (3, 4, 5): one `apply_transition` (dynamics/gauge_dynamics.py:195-259) -- momenta, direction
+    coin and MH uniform drawn on the device, BOTH directions integrated (as the reference does), accept/reject,
+    wrap to [0, 2pi) and the per-step observables;
+  * toy configs (1, 2): one `propose(x, dynamics, do_mh_step=True)` (utils/sampler.py:28-59).
+
+`--config c` selects BASELINE.json configs[c-1]; the default (3) is the configuration the metric is quoted on
+(2D U(1) 8x8, beta 2.0, batch 2048 per GPU, 10 leapfrog steps, GenericNet H=512, fp32) and its line also
+carries a compact `configs` table with the other four workloads at their per-GPU size.
 
 N > 1: a bare `python bench.py --gpus N` starts its own N ranks (child processes through
 torch.distributed.run, before this process touches the GPU); under torch.distributed.run (WORLD_SIZE set) the
-process is a rank.  One rank per GPU: chains are
-independent, so every rank integrates its own 2048 chains (weak scaling) and
-the only exchange is one small RCCL all-reduce of the per-step scalar sums
-(accept probability, |dQ|, count), issued on a side stream.
+process is a rank.  One rank per GPU; chains are independent, so the ranks share nothing but one small RCCL
+all-reduce of the per-step scalar sums (accept probability, |dQ|, count), issued on a side stream.
+  * `--scaling weak`  : every rank integrates the config's per-GPU batch (128 / 4096 / 2048 / 1024 / 2048 chains)
+  * `--scaling strong`: the config's GLOBAL batch (128 / 4096 / 2048 / 8192 / 16384) is cut into N contiguous
+                        shards (l2hmc_amd.dist.shard_bounds): rank r integrates chains [lo_r, hi_r)
+Default: weak for configs 1-3, strong for configs 4 and 5 (BASELINE.json names those as sharded workloads:
+8192 and 16384 chains over 8 GPUs = 1024 and 2048 per GPU; reference: gauge_model.py:942-943, 1008, 1095).
 
-Prints ONE JSON line (rank 0).  `value` counts USEFUL chain-leapfrog steps
-(B*N_LF per transition); the executed count is twice that and is what the
-roofline FLOPs use.
+Prints ONE JSON line (rank 0).  `value` counts USEFUL chain-leapfrog steps (chains x N_LF per step); the
+executed count is twice that (both directions) and is what the roofline FLOPs use.  A secondary leg that
+fails is reported under an "error" key AND makes the process exit non-zero after the line is printed.
 """
 import argparse
 import ctypes as C
@@ -36,28 +42,71 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-L, BETA, EPS, N_LF, BATCH, HID_MULT = 8, 2.0, 0.25, 10, 2048, 4
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 
+# BASELINE.json configs[i-1]; sizes and synthetic inputs as SURVEY.md 8 (sizes table) / 8d state them.
+# `global` = the batch BASELINE.json names; `per_gpu` = what one GPU of the named partition integrates.
+CONFIGS = {
+    1: dict(kind="toy", target="scg", D=2, H=10, N=5, eps=0.1, per_gpu=128, glob=128, scaling="weak",
+            steps=50, warmup=5, prewarm=20,
+            name="2-D strongly-correlated Gaussian, batch 128, 5 LF steps, MLP H=10 (BASELINE.json configs[0])"),
+    2: dict(kind="toy", target="mog", D=2, H=50, N=10, eps=0.1, per_gpu=4096, glob=4096, scaling="weak",
+            steps=50, warmup=5, prewarm=20,
+            name="2-D mixture of Gaussians, batch 4096, 10 LF steps, MLP H=50 (BASELINE.json configs[1])"),
+    3: dict(kind="gauge", L=8, beta=2.0, eps=0.25, N=10, arch="generic", per_gpu=2048, glob=2048, scaling="weak",
+            steps=50, warmup=5, prewarm=150,
+            name="U(1) 8x8 lattice, beta=2.0, batch 2048 per GPU, 10 LF steps, GenericNet H=512 "
+                 "(BASELINE.json configs[2])"),
+    4: dict(kind="gauge", L=16, beta=3.0, eps=0.2, N=15, arch="conv3D", per_gpu=1024, glob=8192, scaling="strong",
+            steps=10, warmup=2, prewarm=6,
+            name="U(1) 16x16 lattice, beta=3.0, batch 8192 sharded over 8 GPUs (1024 per GPU), 15 LF steps, "
+                 "ConvNet3D F=16 H=1024 (BASELINE.json configs[3])"),
+    5: dict(kind="gauge", L=32, beta=4.0, eps=0.1, N=25, arch="generic", per_gpu=2048, glob=16384, scaling="strong",
+            steps=3, warmup=1, prewarm=1,
+            name="U(1) 32x32 lattice, beta=4.0, batch 16384 sharded over 8 GPUs (2048 per GPU), 25 LF steps, "
+                 "GenericNet H=8192 (BASELINE.json configs[4])"),
+}
+HEADLINE_METRIC = "leapfrog-steps/sec (whole node), 8x8 U(1) batch 2048, 10 LF"
 
-def net_macs(D, H):
-    """generic net MACs per call per chain = 2DH + 2H + H^2 + 3HD."""
-    return 2 * D * H + 2 * H + H * H + 3 * H * D
+
+def net_macs(D, H, Ka=None, Kb=None):
+    """dense trunk MACs per call per chain = (Ka + Kb) H + 2H + H^2 + 3HD (generic: Ka = Kb = D)."""
+    Ka = D if Ka is None else Ka
+    Kb = D if Kb is None else Kb
+    return (Ka + Kb) * H + 2 * H + H * H + 3 * H * D
 
 
-def build_dynamics(batch, both_directions=True, arch='generic'):
-    """The product's own constructor (reference initialisation, generic_net.py:39-90) under fixed NumPy seeds;
-    returns the weights/masks as NumPy too, for the cpu_baseline leg."""
-    import l2hmc_amd as la
-    np.random.seed(106)
-    lat = la.GaugeLattice(L, L, 2, 'U1', num_samples=batch, rand=False)
-    dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=EPS, hmc=False, network_arch=arch, num_steps=N_LF,
-                           eps_trainable=True, data_format='channels_last', both_directions=both_directions)
-    if arch != 'generic':
-        return dyn, None, None, None
-    xp = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dyn.position_fn.state_dict().items()}
-    vp = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dyn.momentum_fn.state_dict().items()}
-    return dyn, xp, vp, dyn.mask.cpu().numpy()
+def conv_front_macs(L, F):
+    """both inputs through conv1 (3,3,2) and conv2 (2,2,2): 2 (L L 2 F 18 + (L/2)^2 2F 8F)."""
+    return 2 * (L * L * 2 * F * 18 + (L // 2) ** 2 * 2 * F * 8 * F)
+
+
+def config_macs(cfg):
+    """(MACs per net call per chain, dims dict): FLOPs per chain-LF step = 8 x MACs (4 net calls x 2)."""
+    c = CONFIGS[cfg]
+    if c["kind"] == "toy":
+        D, H = c["D"], c["H"]
+        return net_macs(D, H), dict(D=D, H=H)
+    L = c["L"]
+    D = 2 * L * L
+    if c["arch"] == "generic":
+        H = 4 * D
+        return net_macs(D, H), dict(D=D, H=H, Ka=D, Kb=D)
+    F, H = L, 2 * D
+    nflat = (L // 4) ** 2 * 2 * F
+    return conv_front_macs(L, F) + net_macs(D, H, nflat, nflat), dict(D=D, H=H, Ka=nflat, Kb=nflat, F=F)
+
+
+def rank_chains(cfg, world, rank, scaling):
+    """Chains [lo, hi) of the job's global batch that `rank` integrates, and the global batch.
+    weak: per-GPU batch fixed, global = world x per_gpu.  strong: the config's global batch cut into `world`
+    contiguous shards (l2hmc_amd/dist.py:shard_bounds; SURVEY.md 8e: 1024 / 2048 per GPU at 8 GPUs)."""
+    from l2hmc_amd.dist import shard_bounds
+    c = CONFIGS[cfg]
+    if scaling == "weak":
+        return rank * c["per_gpu"], (rank + 1) * c["per_gpu"], world * c["per_gpu"]
+    lo, hi = shard_bounds(c["glob"], world, rank)
+    return lo, hi, c["glob"]
 
 
 def committed_traffic():
@@ -97,9 +146,9 @@ def self_launch(cmd):
     return subprocess.run(cmd, env=env).returncode
 
 
-def rendezvous_only(world, rank):
+def rendezvous_only(world, rank, cfg, scaling):
     """The cross-rank plumbing of the timed region without the GPU work (CPU test hook): barrier on both sides,
-    MAX over ranks of the elapsed time, rank 0 prints one line."""
+    MAX over ranks of the elapsed time, every rank's chain block [lo, hi) gathered; rank 0 prints one line."""
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -107,42 +156,298 @@ def rendezvous_only(world, rank):
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
+    lo, hi, glob = rank_chains(cfg, world, rank, scaling)
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     ranks = torch.ones(1, dtype=torch.float64)
+    bounds = torch.zeros(world, 2, dtype=torch.int64)
+    bounds[rank, 0], bounds[rank, 1] = lo, hi
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+        dist.all_reduce(bounds, op=dist.ReduceOp.SUM)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": int(ranks.item()),
-                          "max_elapsed_s": float(t.item())}), flush=True)
+                          "max_elapsed_s": float(t.item()), "config": cfg, "scaling": scaling,
+                          "global_batch": glob, "chains": bounds.tolist()}), flush=True)
     return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload builders (the product's own constructors; reference initialisation under fixed NumPy seeds)
+# ---------------------------------------------------------------------------------------------------------------
+def build_gauge(cfg, batch, both_directions=True, arch=None):
+    import l2hmc_amd as la
+    c = CONFIGS[cfg]
+    np.random.seed(106)
+    lat = la.GaugeLattice(c["L"], c["L"], 2, 'U1', num_samples=batch, rand=False)
+    return la.GaugeDynamics(lat, lat.get_energy_function(), eps=c["eps"], hmc=False,
+                            network_arch=arch or c["arch"], num_steps=c["N"], eps_trainable=True,
+                            data_format='channels_last', both_directions=both_directions)
+
+
+def net_state_numpy(net):
+    return {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+
+
+def build_toy(cfg):
+    import l2hmc_amd as la
+    c = CONFIGS[cfg]
+    np.random.seed(106)
+    if c["target"] == "mog":           # mog_model.py:1063-1067, :1120
+        target = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    else:                              # SCGExperiment.ipynb cell 3
+        target = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+    H = c["H"]
+    dyn = la.Dynamics(c["D"], target.get_energy_function(), trajectory_length=c["N"], eps=c["eps"],
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=H))
+    return dyn, target
+
+
+def profile_class(Lh, cls, run, _lib):
+    """(avg us, launches) of kernel class `cls` over `run()`, HIP events on the launch stream."""
+    _lib.check(Lh.l2hmc_profile_begin(cls))
+    run()
+    ms, n = C.c_double(), C.c_int64()
+    _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))
+    return (1e3 * ms.value / n.value if n.value else 0.0), int(n.value)
+
+
+def gauge_kernel_classes(cfg, rows, fused):
+    """(class id, kernel name, algorithmic FLOPs per launch) of the kernels a lattice step launches."""
+    c = CONFIGS[cfg]
+    macs, d = config_macs(cfg)
+    D, H = d["D"], d["H"]
+    if fused:
+        name = ("gauge_traj_fused_kernel<128,512> (whole MCMC step in one launch: draws, both trajectories, "
+                "mix / MH, observables, wrap)" if c["arch"] == "generic" else
+                "gauge_traj_fused_kernel<128,256,64,conv> (whole MCMC step in one launch, conv front-end in LDS)")
+        return [(5, name, 8.0 * macs * rows * c["N"])]
+    out = [(1, "gemm_relu_kernel<.,1> (first dense layer)", 2.0 * rows * H * (d["Ka"] + d["Kb"])),
+           (2, "gemm_relu_kernel<.,2> (hidden dense layer)", 2.0 * rows * H * H),
+           (3, "heads_kernel (S/T/Q + sub-update + log-det)", 2.0 * rows * 3 * D * H)]
+    if c["arch"] == "conv3D":
+        out.append((6, "conv3d_front_kernel (both inputs: conv1+relu+pool, conv2+relu+pool; VALU, priced at the "
+                       "fp32 MFMA rate)", 2.0 * rows * conv_front_macs(c["L"], d["F"])))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one workload: the timed region + its roofline; used for the selected config and for the `configs` table
+# ---------------------------------------------------------------------------------------------------------------
+class Job:
+    """Distributed context of this process."""
+
+    def __init__(self, world, rank, dev, dist):
+        self.world, self.rank, self.dev, self.dist = world, rank, dev, dist
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.dist is None:
+            return dt
+        t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roofline=True, keep=None):
+    """Builds config `cfg` at this rank's share, runs prewarm + W warm-up + EXACTLY K timed steps bracketed by
+    barrier + synchronize, MAX over ranks.  Returns (result dict, state for the secondary legs)."""
+    from l2hmc_amd import _lib
+    import l2hmc_amd as la
+    c = CONFIGS[cfg]
+    lo, hi, glob = rank_chains(cfg, job.world, job.rank, scaling)
+    B = hi - lo
+    if B <= 0:
+        raise SystemExit(f"bench.py: rank {job.rank} has no chains (config {cfg}, {scaling} scaling, "
+                         f"{job.world} ranks)")
+    macs, dims = config_macs(cfg)
+    Lh = _lib.lib()
+    state = {}
+    if c["kind"] == "gauge":
+        from l2hmc_amd import GaugeSampler
+        dyn = build_gauge(cfg, B, both)
+        dyn._seed = 1000 + job.rank                    # independent chains per rank
+        dyn.fused = not layered
+        D = dims["D"]
+        x = torch.empty(B, D, device=job.dev)
+        # hot start (lattice.py:131-135); Philox stream `lo`: every shard of the global batch has its own start
+        _lib.check(Lh.l2hmc_fill_uniform(x.data_ptr(), x.numel(), 103, lo, _lib.stream_ptr()))
+        x.mul_(2 * np.pi)
+        sampler = GaugeSampler(dyn, dist=job.dist)     # transition + wrap + observables; one fused all-reduce
+        stats = sampler.stats
+        beta = c["beta"]
+
+        def step(xc):
+            return sampler.step(xc, beta)[0]
+        state.update(dyn=dyn, sampler=sampler, stats=stats)
+    else:
+        dyn, target = build_toy(cfg)
+        dyn._seed = 1000 + job.rank
+        np.random.seed(102 + job.rank)
+        x = _lib.as_dev(np.asarray(target.get_samples(B), dtype=np.float32), job.dev)   # exact draws of the target
+        stats = None
+
+        def step(xc):
+            return la.propose(xc, dyn, do_mh_step=True)[3][0]
+        state.update(dyn=dyn, target=target)
+
+    # untimed pre-warm, in ADDITION to the W warm-up steps: after the idle seconds of start-up the GPU clock takes
+    # ~20 ms of work to ramp (tools/warmup_probe.py -> profiles/r02_warmup_probe.txt), which a 5-step warm-up would
+    # leak into a 20-step timing (a FIXED count per config: every lattice step carries a collective when sharded)
+    prewarm = c["prewarm"]
+    for i in range(prewarm):
+        x = step(x)
+        if i % 16 == 15:
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        x = step(x)
+    if stats is not None:
+        stats.wait()                               # the untimed steps' scalars are folded before the clock starts
+    job.barrier()
+    history = []                                   # references only: no device work in the timed region
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        x = step(x)
+        if keep:
+            history.append(x)
+    if stats is not None:
+        stats.join()                               # every step's all-reduce is ordered before the synchronize
+    job.barrier()
+    dt = time.perf_counter() - t0
+    if stats is not None:
+        stats.wait()                               # host-side bookkeeping of the step scalars: not part of a step
+    dt = job.max_over_ranks(dt)
+
+    ndir = 2 if both else 1
+    useful = glob * c["N"] * steps
+    res = {"cfg": cfg, "workload": c["name"], "value": useful / dt, "ms_per_step": 1e3 * dt / steps,
+           "steps": steps, "warmup": warmup, "prewarm_steps_untimed": prewarm, "scaling": scaling,
+           "global_batch": glob, "chains_this_rank": [lo, hi], "num_steps": c["N"], "eps": c["eps"],
+           "directions_integrated": ndir, "executed_chain_lf_per_step": ndir * glob * c["N"],
+           "algorithmic_flops_per_chain_lf": 8 * macs,
+           "whole_step_tflops": ndir * glob * c["N"] * 8 * macs / (dt / steps) / 1e12 / job.world}
+    res["whole_step_frac"] = res["whole_step_tflops"] / PEAK_F32_MFMA_TFLOPS
+    if c["kind"] == "gauge":
+        res["lattice"], res["beta"] = [c["L"], c["L"]], c["beta"]
+        res["mean_accept_prob"] = stats.mean_accept()
+    state.update(x=x, step=step, history=history, B=B, dt=dt)
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream (every rank runs the profiled steps
+    #      -- lattice steps contain the per-step collective -- only rank 0 reports)
+    if roofline:
+        rows = ndir * B
+        if c["kind"] == "toy":
+            classes = [(7, "small_traj_mfma_kernel (one launch per propose: Philox draws, both trajectories, mix, MH)",
+                        8.0 * macs * 2 * B * c["N"])]
+        else:
+            from l2hmc_amd import _lib as _l
+            plan = state["dyn"]._plan()
+            fused = (not layered) and _l.lib().l2hmc_gauge_plan_fused(C.byref(plan)) == 1
+            classes = gauge_kernel_classes(cfg, rows, fused)
+        nprof = max(1, min(steps, 20))
+        per = []
+        for cls, name, flops in classes:
+            def run():
+                xs = x
+                for _ in range(nprof):
+                    xs = step(xs)
+            us, n = profile_class(Lh, cls, run, _lib)
+            if n:
+                per.append(dict(kernel=name, launches=n, avg_us=us, flops_per_launch=flops,
+                                tflops=flops / (us * 1e-6) / 1e12, frac=flops / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS))
+        if stats is not None:
+            stats.wait()
+        if per:
+            dom = max(per, key=lambda d: d["avg_us"] * d["launches"])
+            res["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"],
+                               "avg_launch_us": dom["avg_us"], "algorithmic_flops_per_launch": dom["flops_per_launch"],
+                               "all_kernels": per, "whole_step_tflops": res["whole_step_tflops"],
+                               "whole_step_frac": res["whole_step_frac"]}
+    return res, state
+
+
+def cpu_baseline_for(cfg, state):
+    """The reference's CPU path (op-for-op torch-CPU port, oracle/cpu_baseline.py) on a bounded sample of the
+    same workload, rank 0 at N = 1 only."""
+    from oracle import cpu_baseline as cb
+    c = CONFIGS[cfg]
+    dyn = state["dyn"]
+    if c["kind"] == "toy":
+        from oracle import dynamics as ogen
+        if c["target"] == "mog":
+            target = ogen.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+        else:
+            target = ogen.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+        r = cb.time_cpu_toy_baseline(target, c["N"], c["eps"], c["per_gpu"], net_state_numpy(dyn.XNet),
+                                     net_state_numpy(dyn.VNet), dyn.mask.cpu().numpy(), budget_s=10.0)
+        sample, what = c["per_gpu"], "propose calls (both directions)"
+    else:
+        # bounded sample: the full 2048 chains at cfg 3 (0.3 s per call); fewer where one call would take minutes
+        sample = {3: 2048, 4: 128, 5: 32}[cfg]
+        r = cb.time_cpu_baseline(c["L"], c["L"], c["N"], c["eps"], c["beta"], sample,
+                                 net_state_numpy(dyn.position_fn), net_state_numpy(dyn.momentum_fn),
+                                 dyn.mask.cpu().numpy(), budget_s={3: 15.0, 4: 12.0, 5: 10.0}[cfg],
+                                 min_calls={3: 2, 4: 2, 5: 1}[cfg], arch=c["arch"],
+                                 threads=None if cfg != 5 else "all")
+        what = "apply_transition calls (both directions)"
+    return {"value": r["value"], "unit": "chain-leapfrog-steps/s", "cores": r["cores"], "kind": "port",
+            "sample": f"{r['calls']} timed {what} on {sample} chains of the same lattice/net/LF config, torch-CPU "
+                      f"fp32 op-for-op port of the reference graph, median {r['seconds']:.3f} s per call; "
+                      f"{r['cores']} threads of {r['cpus_available']} usable CPUs"}
+
+
+def ess_of(history, chain_stats):
+    """ESS per MCMC step with the reference's estimator (func_utils.py:45-54,114-120) on (cos, sin) of the links."""
+    X = torch.stack(history).cpu().numpy()
+    feats = np.concatenate([np.cos(X), np.sin(X)], axis=2)
+    feats = feats - feats.mean(axis=(0, 1), keepdims=True)
+    A = chain_stats.acl_spectrum(feats, 1.0)
+    return float(chain_stats.ESS(A / A[0]))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per config: 50 / 50 / 50 / 10 / 3)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[c-1]; 3 = the configuration the metric is quoted on")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: per-GPU batch fixed; strong: the config's global batch sharded over the ranks "
+                         "(default: weak for configs 1-3, strong for 4 and 5)")
     ap.add_argument("--selected-only", action="store_true",
                     help="integrate only the direction each chain's coin selects (not the reference's work)")
     ap.add_argument("--layered", action="store_true", help="use the layer-by-layer kernels (no fused trajectory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs-table", action="store_true",
+                    help="skip the compact table of the other BASELINE configs in the default line")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
     ap.add_argument("--no-trained-ess", action="store_true",
                     help="skip the 250-step training run + ESS/sec of the trained sampler (N = 1 only)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="test hook (CPU, gloo): start the ranks, barrier, max-over-ranks reduction, print "
-                         "{'rendezvous_only': true, ...} and exit -- no measurement, no GPU")
+                         "{'rendezvous_only': true, ..., 'chains': [[lo, hi) per rank]} and exit -- no GPU")
     args = ap.parse_args()
 
     cmd = launch_command(args.gpus, os.environ, sys.argv[1:])
     if cmd is not None:                           # before anything initialises the GPU in this process
         raise SystemExit(self_launch(cmd))
 
+    cfg = args.config
+    c = CONFIGS[cfg]
+    scaling = args.scaling or c["scaling"]
+    steps = args.steps if args.steps is not None else c["steps"]
+    warmup = args.warmup if args.warmup is not None else c["warmup"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,7 +455,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py "
                          f"--gpus N` or through torch.distributed.run with --nproc-per-node N)")
     if args.rendezvous_only:
-        raise SystemExit(rendezvous_only(world, rank))
+        raise SystemExit(rendezvous_only(world, rank, cfg, scaling))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0 over gloo.
@@ -176,303 +481,236 @@ def main():
 
     from l2hmc_amd import _lib, GaugeSampler, stats as chain_stats
     dev = torch.device("cuda", local_rank)
+    job = Job(world, rank, dev, dist)
     both = not args.selected_only
-    dyn, xp, vp, masks = build_dynamics(BATCH, both)
-    dyn._seed = 1000 + rank                       # independent chains per rank
-    dyn.fused = not args.layered
-    D = 2 * L * L
-    x = torch.empty(BATCH, D, device=dev)
-    _lib.check(_lib.lib().l2hmc_fill_uniform(x.data_ptr(), x.numel(), 103 + rank, 0, _lib.stream_ptr()))
-    x.mul_(2 * np.pi)                             # hot start, lattice.py:131-135
-    sampler = GaugeSampler(dyn, dist=dist)       # transition + device-side wrap + per-step observables
-    stats = sampler.stats                        # one fused all-reduce of the step's scalar sums
+    failed = []                                   # secondary legs that threw: reported AND a non-zero exit
 
-    def step(x):
-        return sampler.step(x, BETA)[0]
-
-    # untimed pre-warm, in ADDITION to the W warm-up steps: after the idle seconds of start-up the GPU clock takes
-    # ~20 ms of work to ramp (tools/warmup_probe.py -> profiles/r02_warmup_probe.txt: the first 10 steps after an
-    # idle period run 2.14 -> 1.70 ms, steady state 1.68), which a 5-step warm-up would leak into a 20-step timing
-    # (a FIXED count: every step carries a collective when sharded, so all ranks must run the same number)
-    prewarm = 150
-    for i in range(prewarm):
-        x = step(x)
-        if i % 16 == 15:
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        x = step(x)
-    stats.wait()                                  # the untimed steps' scalars are folded before the clock starts
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    history = []                                  # references only: no device work in the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x = step(x)
-        history.append(x)
-    stats.join()                                  # every step's all-reduce is ordered before the synchronize below
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stats.wait()                                  # host-side bookkeeping of the step scalars: not part of a step
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    accept_rate = stats.mean_accept()
-
-    useful = world * BATCH * N_LF * args.steps
-    value = useful / dt
+    res, st = run_workload(job, cfg, scaling, steps, warmup, both=both, layered=args.layered,
+                           roofline=not args.no_roofline, keep=(c["kind"] == "gauge" and cfg == 3))
+    lo, hi = res["chains_this_rank"]
+    short = {1: "2-D SCG batch 128, 5 LF", 2: "2-D MoG batch 4096, 10 LF", 4: "16x16 U(1) conv3D batch 8192, 15 LF",
+             5: "32x32 U(1) batch 16384, 25 LF"}
     out = {
-        "metric": "leapfrog-steps/sec (whole node), 8x8 U(1) batch 2048, 10 LF",
-        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "prewarm_steps_untimed": prewarm, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "U(1) 8x8 lattice, beta=2.0, batch 2048 per GPU, 10 LF steps, GenericNet H=512 "
-                               "(BASELINE.json configs[2])",
-                   "global_batch": world * BATCH, "lattice": [L, L], "num_steps": N_LF, "eps": EPS, "beta": BETA,
-                   "directions_integrated": 2 if both else 1,
-                   "executed_chain_lf_per_step": (2 if both else 1) * BATCH * N_LF * world,
-                   "parallelism": f"chains sharded over {world} GPU(s), weights replicated",
-                   "mean_accept_prob": accept_rate},
+        "metric": HEADLINE_METRIC if cfg == 3 else f"leapfrog-steps/sec (whole node), {short[cfg]}",
+        "value": res["value"], "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "prewarm_steps_untimed": res["prewarm_steps_untimed"], "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": res["workload"], "baseline_config": cfg, "global_batch": res["global_batch"],
+                   "chains_rank0": [lo, hi], "num_steps": res["num_steps"], "eps": res["eps"],
+                   "directions_integrated": res["directions_integrated"],
+                   "executed_chain_lf_per_step": res["executed_chain_lf_per_step"],
+                   "algorithmic_flops_per_chain_lf": res["algorithmic_flops_per_chain_lf"],
+                   "parallelism": f"chains sharded over {world} GPU(s) ({scaling} scaling), weights replicated"},
     }
+    for k in ("lattice", "beta", "mean_accept_prob"):
+        if k in res:
+            out["config"][k] = res[k]
+    if "roofline" in res:
+        out["roofline"] = res["roofline"]
+    x, step, dyn = st["x"], st["step"], st["dyn"]
 
-    # ---- secondary metric: ESS/sec with the reference's estimator (func_utils.py:45-54,114-120) on
-    #      (cos, sin) of the links of rank 0's chains over the timed steps, normalised by the lag-0 term
-    if rank == 0 and args.steps >= 8:
-        X = torch.stack(history[-min(args.steps, 64):]).cpu().numpy()
-        feats = np.concatenate([np.cos(X), np.sin(X)], axis=2)
-        feats = feats - feats.mean(axis=(0, 1), keepdims=True)
-        A = chain_stats.acl_spectrum(feats, 1.0)
-        ess = float(chain_stats.ESS(A / A[0]))
-        out["config"]["ess_per_mcmc_step"] = ess
-        out["config"]["ess_per_sec_whole_job"] = ess * world * BATCH * args.steps / dt
-    history.clear()
+    if cfg == 3:
+        sampler, stats, BATCH = st["sampler"], st["stats"], st["B"]
+        beta, n_lf = c["beta"], c["N"]
+        dt = st["dt"]
+        # ---- secondary metric: ESS/sec with the reference's estimator on rank 0's chains over the timed steps
+        if rank == 0 and steps >= 8:
+            ess = ess_of(st["history"][-min(steps, 64):], chain_stats)
+            out["config"]["ess_per_mcmc_step"] = ess
+            out["config"]["ess_per_sec_whole_job"] = ess * res["global_batch"] * steps / dt
+        st["history"].clear()
 
-    # ---- roofline of the dominant kernel, HIP events on the launch stream ----
-    # (every rank runs the profiled steps -- they contain the per-step collective -- only rank 0 reports)
-    if not args.no_roofline:
-        Lh = _lib.lib()
-        rows = (2 if both else 1) * BATCH
-        Hd = HID_MULT * D
-        per_class = {}
-        # the ESS estimate above was host work (seconds of idle GPU): ramp the clock again before the event timing
-        xs = x
-        for i in range(100):
-            xs = step(xs)
-        stats.wait()
-        # algorithmic FLOPs per launch: SURVEY.md 8 sizes table (8 x net MACs per chain-LF step)
-        for cls, name, flops in ((5, "gauge_traj_fused_kernel<128,512> (whole MCMC step in one launch: draws, both "
-                                     "trajectories, mix / MH, observables, wrap)",
-                                  8.0 * net_macs(D, Hd) * rows * N_LF),
-                                 (1, "gemm_relu_kernel<64,1> (first layer)", 2.0 * rows * Hd * 2 * D),
-                                 (2, "gemm_relu_kernel<64,2> (hidden layer)", 2.0 * rows * Hd * Hd),
-                                 (3, "heads_kernel (S/T/Q + update)", 2.0 * rows * 3 * D * Hd)):
-            _lib.check(Lh.l2hmc_profile_begin(cls))
+        if "roofline" in out and not args.layered:
+            Lh = _lib.lib()
+            # the ESS estimate above was host work (seconds of idle GPU): ramp the clock again and re-time the step
+            # kernel, so that `roofline` describes the kernel at the clocks of the timed region
             xs = x
-            for _ in range(args.steps):
+            for _ in range(100):
                 xs = step(xs)
-            ms, n = C.c_double(), C.c_int64()
-            _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))
-            per_class[cls] = dict(kernel=name, launches=n.value, avg_us=1e3 * ms.value / max(n.value, 1),
-                                  flops_per_launch=flops,
-                                  tflops=flops / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0)
-        stats.wait()
-        per_class = {k: v for k, v in per_class.items() if v["launches"]}
-        dom = max(per_class.values(), key=lambda d: d["avg_us"] * d["launches"])
-        # The step kernel also draws the momenta and finishes the step (mix, MH, observables, wrap).  The same kernel
-        # launched for the trajectories alone (l2hmc_gauge_trajectory: same rows, same FLOPs, no step prologue /
-        # epilogue) separates the integrator's MFMA efficiency from that fixed per-step work.
-        traj_only = None
-        if not args.layered:
+            stats.wait()
+            D, Hd = 2 * c["L"] ** 2, 8 * c["L"] ** 2
+            rows = (2 if both else 1) * BATCH
+
+            def run():
+                xs = x
+                for _ in range(steps):
+                    xs = step(xs)
+            us, n = profile_class(Lh, 5, run, _lib)
+            stats.wait()
+            if n:
+                flops = 8.0 * net_macs(D, Hd) * rows * n_lf
+                tf = flops / (us * 1e-6) / 1e12
+                out["roofline"].update(achieved=tf, frac=tf / PEAK_F32_MFMA_TFLOPS, avg_launch_us=us)
+                out["roofline"]["all_kernels"][0].update(avg_us=us, launches=n, tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS)
+            # The step kernel also draws the momenta and finishes the step (mix, MH, observables, wrap).  The same
+            # kernel launched for the trajectories alone (l2hmc_gauge_trajectory: same rows, same FLOPs, no step
+            # prologue / epilogue) separates the integrator's MFMA efficiency from that fixed per-step work.
             x2 = torch.cat([x, x]).contiguous()
             v2 = dyn._normal(tuple(x2.shape))
             for _ in range(3):
-                dyn.transition_kernel(x2, BETA, forward=True, momentum=v2)
-            _lib.check(Lh.l2hmc_profile_begin(5))
-            for _ in range(20):
-                dyn.transition_kernel(x2, BETA, forward=True, momentum=v2)
-            ms, n = C.c_double(), C.c_int64()
-            _lib.check(Lh.l2hmc_profile_end(C.byref(ms), C.byref(n)))
-            if n.value:
-                us = 1e3 * ms.value / n.value
-                tf = 8.0 * net_macs(D, Hd) * x2.shape[0] * N_LF / (us * 1e-6) / 1e12
-                traj_only = {"what": "the same kernel launched for the two trajectories alone (l2hmc_gauge_trajectory, "
-                                     f"{x2.shape[0]} rows x {N_LF} LF): no draws, no mix / MH / observables / wrap",
-                             "avg_launch_us": us, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS}
-        # fabric-side bytes per launch of the fused kernel at this exact shape: read from the newest committed PMC
-        # summary (tools/pmc_collect.sh + tools/pmc_summary.py -> profiles/rNN_pmc_fused_kernel.json); null if the
-        # dominant kernel is another one or no summary is committed -- never a literal
-        traffic, traffic_src = None, None
-        if dom["kernel"].startswith("gauge_traj_fused") and both:
-            traffic, traffic_src = committed_traffic()
-        out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "bytes per launch, fabric side: 2 x FETCH_SIZE + WRITE_SIZE from separate "
-                                           f"rocprofv3 --pmc passes ({traffic_src})",
-                           "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
-                           "algorithmic_flops_per_launch": dom["flops_per_launch"],
-                           "all_kernels": list(per_class.values()), "trajectory_only": traj_only,
-                           "whole_step_tflops": (2 if both else 1) * BATCH * N_LF * 8 * net_macs(D, Hd)
-                           / (dt / args.steps) / 1e12}
+                dyn.transition_kernel(x2, beta, forward=True, momentum=v2)
+            us, n = profile_class(Lh, 5, lambda: [dyn.transition_kernel(x2, beta, forward=True, momentum=v2)
+                                                  for _ in range(20)], _lib)
+            if n:
+                tf = 8.0 * net_macs(D, Hd) * x2.shape[0] * n_lf / (us * 1e-6) / 1e12
+                out["roofline"]["trajectory_only"] = {
+                    "what": "the same kernel launched for the two trajectories alone (l2hmc_gauge_trajectory, "
+                            f"{x2.shape[0]} rows x {n_lf} LF): no draws, no mix / MH / observables / wrap",
+                    "avg_launch_us": us, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS}
+            # fabric-side bytes per launch of the fused kernel at this exact shape: read from the newest committed
+            # PMC summary (tools/pmc_collect.sh + tools/pmc_summary.py -> profiles/rNN_pmc_fused_kernel.json);
+            # null if no summary is committed or the shape differs -- never a literal
+            if both and scaling == "weak":
+                traffic, traffic_src = committed_traffic()
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_unit"] = ("bytes per launch, fabric side: 2 x FETCH_SIZE + WRITE_SIZE from "
+                                                   f"separate rocprofv3 --pmc passes ({traffic_src})")
 
-    # ---- the same workload with the reference's CLI-default architecture (conv3D, gauge_model.py:2307) ----
-    if rank == 0 and world == 1 and not args.no_roofline:
-        cdyn = build_dynamics(BATCH, both, arch='conv3D')[0]
-        cdyn.set_masks(masks)
-        csmp = GaugeSampler(cdyn)
-        xc = x.clone()
-        for _ in range(3):
-            xc = csmp.step(xc, BETA)[0]
-        torch.cuda.synchronize()
-        tc0 = time.perf_counter()
-        for _ in range(20):
-            xc = csmp.step(xc, BETA)[0]
-        torch.cuda.synchronize()
-        tcd = (time.perf_counter() - tc0) / 20
-        out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
-                                        "chain_leapfrog_steps_per_s": BATCH * N_LF / tcd}
+        # ---- the same workload with the reference's CLI-default architecture (conv3D, gauge_model.py:2307) ----
+        if rank == 0 and world == 1 and not args.no_roofline:
+            try:
+                cdyn = build_gauge(3, BATCH, both, arch='conv3D')
+                cdyn.set_masks(dyn.mask.cpu().numpy())
+                csmp = GaugeSampler(cdyn)
+                xc = x.clone()
+                for _ in range(3):
+                    xc = csmp.step(xc, beta)[0]
+                torch.cuda.synchronize()
+                tc0 = time.perf_counter()
+                for _ in range(20):
+                    xc = csmp.step(xc, beta)[0]
+                torch.cuda.synchronize()
+                tcd = (time.perf_counter() - tc0) / 20
+                out["config"]["conv3D_arch"] = {"net": "ConvNet3D F=8, H=256", "ms_per_step": 1e3 * tcd,
+                                                "chain_leapfrog_steps_per_s": BATCH * n_lf / tcd}
+                if not args.no_train:             # its training step (taped K1c forward, layered reverse pass)
+                    from l2hmc_amd.gauge_trainer import GaugeTrainer
+                    ctr = GaugeTrainer(cdyn, lr_init=1e-4)
+                    for _ in range(2):
+                        ctr.train_step(x, beta)
+                    torch.cuda.synchronize()
+                    tq0 = time.perf_counter()
+                    for _ in range(10):
+                        ctr.train_step(x, beta)
+                    torch.cuda.synchronize()
+                    out["config"]["conv3D_arch"]["train_ms_per_step"] = 1e3 * (time.perf_counter() - tq0) / 10
+                del cdyn, csmp
+            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
+                out["config"].setdefault("conv3D_arch", {})["error"] = repr(e)
+                failed.append("conv3D_arch")
+
+        # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
+        #      takes part because the gradient bucket is all-reduced (f1/f2) ----
         if not args.no_train:
-            try:                                   # its training step (taped K1c forward, layered reverse pass)
-                from l2hmc_amd.gauge_trainer import GaugeTrainer
-                ctr = GaugeTrainer(cdyn, lr_init=1e-4)
-                for _ in range(2):
-                    ctr.train_step(x, BETA)
+            from l2hmc_amd.gauge_trainer import GaugeTrainer
+            ok, err, tr = 1, "", None
+            try:
+                tdyn = build_gauge(3, BATCH, both)
+                tdyn._seed = 2000 + rank
+                tr = GaugeTrainer(tdyn, lr_init=1e-4, dist=dist)
+                saved, tr.dist = tr.dist, None
+                tr.train_step(x, beta)                # local rehearsal: no collective yet
+                tr.dist = saved
                 torch.cuda.synchronize()
-                tq0 = time.perf_counter()
-                for _ in range(10):
-                    ctr.train_step(x, BETA)
-                torch.cuda.synchronize()
-                out["config"]["conv3D_arch"]["train_ms_per_step"] = 1e3 * (time.perf_counter() - tq0) / 10
-            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line
-                out["config"]["conv3D_arch"]["train_error"] = repr(e)
+            except Exception as e:                    # noqa: BLE001 -- reported in the JSON line
+                ok, err = 0, repr(e)
+            if dist is not None:                      # only enter the collective steps if every rank can
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item()) if ok else 0
+            if ok:
+                nt = 10
+                tr.train_step(x, beta)
+                job.barrier()
+                tt0 = time.perf_counter()
+                for _ in range(nt):
+                    loss = tr.train_step(x, beta)[0]
+                job.barrier()
+                ttd = job.max_over_ranks((time.perf_counter() - tt0) / nt)
+                out["config"]["train_step"] = {
+                    "what": "loss + hand-written reverse pass + gradient all-reduce + Adam, 2048 x-chains and 2048 "
+                            "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
+                    "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
+                    "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss),
+                    "grad_buckets": int(tr.last_bucket_count) if tr.dist is not None else 0}
+                if world == 1 and not args.no_trained_ess:
+                    # the secondary metric with TRAINED networks: a short training run (same shape), then ESS/sec
+                    # of the sampler with the estimator used above (untrained networks barely move a chain)
+                    try:
+                        xt = x
+                        for i in range(250):
+                            _, xo, _, _ = tr.train_step(xt, beta)
+                            xt = sampler.wrap(xo)
+                        tsm = GaugeSampler(tdyn)
+                        for _ in range(20):
+                            xt = tsm.step(xt, beta)[0]
+                        torch.cuda.synchronize()
+                        te0 = time.perf_counter()
+                        hist2 = []
+                        for _ in range(64):
+                            xt = tsm.step(xt, beta)[0]
+                            hist2.append(xt)
+                        tsm.stats.wait()
+                        torch.cuda.synchronize()
+                        ted = time.perf_counter() - te0
+                        ess2 = ess_of(hist2, chain_stats)
+                        out["config"]["after_260_train_steps"] = {
+                            "mean_accept_prob": tsm.stats.mean_accept(), "eps": float(tdyn.eps),
+                            "ess_per_mcmc_step": ess2, "ess_per_sec_whole_job": ess2 * BATCH * 64 / ted,
+                            "ms_per_mcmc_step": 1e3 * ted / 64}
+                        del hist2, tsm
+                    except Exception as e:                # noqa: BLE001
+                        out["config"]["after_260_train_steps"] = {"error": repr(e)}
+                        failed.append("after_260_train_steps")
+            else:
+                out["config"]["train_step"] = {"error": err or "another rank failed"}
+                failed.append("train_step")
+            del tr
 
-    # ---- secondary: BASELINE.json configs[1], the 2-D mixture of Gaussians (mog_model.py): 4096 chains per GPU,
-    #      10 LF steps, `propose` = forward + backward trajectories of every chain in one launch + mix/accept.
-    #      Chains are independent: every rank runs its own 4096 (no collective); rank 0 reports its own time.
-    try:
-        import l2hmc_amd as la
-        np.random.seed(106)
-        gmm = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
-        mdyn = la.Dynamics(2, gmm.get_energy_function(), trajectory_length=10, eps=0.1,
-                           net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=50))
-        mx = torch.randn(4096, 2, device=dev)
-        for _ in range(5):
-            mx = la.propose(mx, mdyn, do_mh_step=True)[3][0]
-        torch.cuda.synchronize()
-        tm0 = time.perf_counter()
-        for _ in range(50):
-            mx = la.propose(mx, mdyn, do_mh_step=True)[3][0]
-        torch.cuda.synchronize()
-        tmd = (time.perf_counter() - tm0) / 50
-        out["config"]["mog_cfg2"] = {
-            "workload": "2-D mixture of Gaussians, 4096 chains per GPU, 10 LF steps, MLP H=50 (BASELINE.json configs[1])",
-            "ms_per_propose": 1e3 * tmd, "chain_leapfrog_steps_per_s": world * 4096 * 10 / tmd,
-            # 4 network calls per LF step and direction; MACs per call and chain: two 2 x 50 input layers, the time
-            # layer, 50 x 50 hidden, three 50 x 2 heads
-            "algorithmic_tflops": 2 * 4096 * 40 * 2 * (2 * 2 * 50 + 2 * 50 + 50 * 50 + 3 * 2 * 50) / tmd / 1e12,
-            "frac_of_fp32_mfma_peak": 2 * 4096 * 40 * 2 * (2 * 2 * 50 + 2 * 50 + 50 * 50 + 3 * 2 * 50) / tmd / 1e12
-            / PEAK_F32_MFMA_TFLOPS,
-            "bound": "latency (one launch per propose: Philox draws, both trajectories, mix and MH in the kernel; a "
-                     "wave walks 40 dependent network calls for its 8 chains x 2 directions -- 512 waves on 1024 "
-                     "SIMDs; hidden layer and heads on 16x16x4 fp32 MFMAs with register-resident weights, DESIGN.md K4)"}
-    except Exception as e:                        # noqa: BLE001
-        out["config"]["mog_cfg2"] = {"error": repr(e)}
-
-    # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
-    #      takes part because the gradient bucket is all-reduced (f1/f2) ----
-    if not args.no_train:
-        from l2hmc_amd.gauge_trainer import GaugeTrainer
-        ok, err, tr = 1, "", None
-        try:
-            tdyn = build_dynamics(BATCH, both)[0]
-            tdyn._seed = 2000 + rank
-            tr = GaugeTrainer(tdyn, lr_init=1e-4, dist=dist)
-            saved, tr.dist = tr.dist, None
-            tr.train_step(x, BETA)                # local rehearsal: no collective yet
-            tr.dist = saved
-            torch.cuda.synchronize()
-        except Exception as e:                    # noqa: BLE001 -- reported in the JSON line
-            ok, err = 0, repr(e)
-        if dist is not None:                      # only enter the collective steps if every rank can
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item()) if ok else 0
-        if ok:
-            nt = 10
-            tr.train_step(x, BETA)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            tt0 = time.perf_counter()
-            for _ in range(nt):
-                loss = tr.train_step(x, BETA)[0]
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            ttd = (time.perf_counter() - tt0) / nt
-            if dist is not None:
-                t = torch.tensor([ttd], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ttd = float(t.item())
-            out["config"]["train_step"] = {
-                "what": "loss + hand-written reverse pass + gradient all-reduce + Adam, 2048 x-chains and 2048 "
-                        "auxiliary chains per GPU, 10 LF (gauge_model.py:799-830, :942-969)",
-                "ms_per_step": 1e3 * ttd, "train_chains_per_s": world * BATCH / ttd,
-                "grad_bucket_bytes": int(tr.grads.numel() * 4), "loss": float(loss),
-                "grad_buckets": int(tr.last_bucket_count) if tr.dist is not None else 0}
-            if world == 1 and not args.no_trained_ess:
-                # the secondary metric with TRAINED networks: a short training run (same shape), then ESS/sec of
-                # the sampler with the estimator used above (untrained networks barely move a chain)
-                try:
-                    xt = x
-                    for i in range(250):
-                        _, xo, _, _ = tr.train_step(xt, BETA)
-                        xt = sampler.wrap(xo)
-                    tsm = GaugeSampler(tdyn)
-                    for _ in range(20):
-                        xt = tsm.step(xt, BETA)[0]
-                    torch.cuda.synchronize()
-                    te0 = time.perf_counter()
-                    hist2 = []
-                    for _ in range(64):
-                        xt = tsm.step(xt, BETA)[0]
-                        hist2.append(xt)
-                    tsm.stats.wait()
-                    torch.cuda.synchronize()
-                    ted = time.perf_counter() - te0
-                    X2 = torch.stack(hist2).cpu().numpy()
-                    f2 = np.concatenate([np.cos(X2), np.sin(X2)], axis=2)
-                    f2 = f2 - f2.mean(axis=(0, 1), keepdims=True)
-                    A2 = chain_stats.acl_spectrum(f2, 1.0)
-                    ess2 = float(chain_stats.ESS(A2 / A2[0]))
-                    out["config"]["after_260_train_steps"] = {
-                        "mean_accept_prob": tsm.stats.mean_accept(), "eps": float(tdyn.eps),
-                        "ess_per_mcmc_step": ess2, "ess_per_sec_whole_job": ess2 * BATCH * 64 / ted,
-                        "ms_per_mcmc_step": 1e3 * ted / 64}
-                except Exception as e:                # noqa: BLE001
-                    out["config"]["after_260_train_steps"] = {"error": repr(e)}
-        else:
-            out["config"]["train_step"] = {"error": err or "another rank failed"}
-
-    # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample ----
+    # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample, rank 0 at N = 1 ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.cpu_baseline import time_cpu_baseline
-        sample_b = BATCH          # the whole per-GPU batch: ~0.5 s per call with a sane thread count
-        cb = time_cpu_baseline(L, L, N_LF, EPS, BETA, sample_b, xp, vp, masks, budget_s=15.0)
-        out["cpu_baseline"] = {"value": cb["value"], "unit": "chain-leapfrog-steps/s", "cores": cb["cores"],
-                               "kind": "port",
-                               "sample": f"{cb['calls']} timed apply_transition calls (both directions) on "
-                                         f"{sample_b} chains (the full per-GPU batch), same lattice/net/LF config, torch-CPU fp32, "
-                                         f"median {cb['seconds']:.3f} s per call; thread count probed for the best "
-                                         f"throughput ({cb['cores']} of {cb['cpus_available']} usable CPUs)"}
+        out["cpu_baseline"] = cpu_baseline_for(cfg, st)
+
+    # ---- the other BASELINE configs at their per-GPU size (N = 1, default line only): compact table ----
+    if cfg == 3 and world == 1 and not args.no_configs_table and not args.layered and both:
+        table = [{"cfg": 3, "workload": c["name"], "chains": st["B"], "ms_per_step": out["ms_per_step"],
+                  "value": out["value"], "tflops": out.get("roofline", {}).get("whole_step_tflops"),
+                  "frac": out.get("roofline", {}).get("whole_step_frac"),
+                  "kernel": out.get("roofline", {}).get("kernel"),
+                  "kernel_avg_us": out.get("roofline", {}).get("avg_launch_us"),
+                  "kernel_frac": out.get("roofline", {}).get("frac")}]
+        del st, x, dyn
+        torch.cuda.empty_cache()
+        for oc, (k, w) in ((1, (50, 5)), (2, (50, 5)), (4, (5, 2)), (5, (3, 1))):
+            try:
+                r, s2 = run_workload(job, oc, "weak", k, w, roofline=not args.no_roofline)
+                rf = r.get("roofline", {})
+                table.append({"cfg": oc, "workload": r["workload"], "chains": s2["B"], "ms_per_step": r["ms_per_step"],
+                              "value": r["value"], "tflops": r["whole_step_tflops"], "frac": r["whole_step_frac"],
+                              "kernel": rf.get("kernel"), "kernel_avg_us": rf.get("avg_launch_us"),
+                              "kernel_frac": rf.get("frac"),
+                              "kernels": [{"kernel": q["kernel"].split(" ")[0], "avg_us": q["avg_us"], "frac": q["frac"],
+                                           "launches_per_step": q["launches"] / max(1, min(k, 20))}
+                                          for q in rf.get("all_kernels", [])]})
+                del s2, r
+            except Exception as e:                # noqa: BLE001
+                table.append({"cfg": oc, "error": repr(e)})
+                failed.append(f"configs[{oc}]")
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+        table.sort(key=lambda t: t["cfg"])
+        out["configs"] = table
+        out["configs_note"] = ("every BASELINE.json config on ONE GPU at its per-GPU size (configs 4 and 5: the 1/8 "
+                               "shard of the 8-GPU partition, 1024 and 2048 chains); value = useful chain-LF/s, "
+                               "tflops / frac = executed algorithmic FLOPs of the whole step against the fp32 MFMA "
+                               "peak; `python bench.py --config c [--gpus N]` runs one of them as the headline")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        print(f"bench.py: secondary leg(s) failed: {failed}", file=sys.stderr, flush=True)
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -200,6 +200,11 @@ typedef struct l2hmc_gauge_plan {
 
 size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);
 
+/* Which kernels a plan runs through (no reference counterpart; for callers that report or size by it):
+ * 1 = a whole-trajectory kernel exists for this shape and L2HMC_PLAN_LAYERED is not set, 0 = layer by layer,
+ * negative = invalid plan (l2hmc_last_error says why). */
+int l2hmc_gauge_plan_fused(const l2hmc_gauge_plan* plan);
+
 /* One augmented leapfrog step IN PLACE on x, v: [rows][D]; dir: [rows] int32 per
  * row (0 fwd, 1 bwd), or NULL = all forward.  `step` is the loop counter t of
  * transition_kernel: backward rows use index num_steps-1-step for time and
@@ -430,6 +435,7 @@ int l2hmc_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, l2
  * recorded one after the other); not for use while capturing a graph.
  *   1 = first dense layer   2 = hidden dense layer   3 = heads (+update)
  *   4 = u1_action_force     5 = fused whole-trajectory kernel
+ *   6 = ConvNet3D front-end 7 = toy-target trajectory kernel (l2hmc_small_*)
  * ------------------------------------------------------------------------ */
 int l2hmc_profile_begin(int32_t kernel_class);
 int l2hmc_profile_end(double* total_ms, int64_t* launches);

@@ -81,6 +81,7 @@ _PROTOS = {
     "l2hmc_accept_prob": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
     "l2hmc_mix_accept": (C.c_int, [_P] * 9 + [_I32, _I64, _I32, _P, _P, _P, _P, _P]),
     "l2hmc_gauge_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
+    "l2hmc_gauge_plan_fused": (C.c_int, [C.POINTER(GaugePlan)]),
     "l2hmc_gauge_leapfrog": (C.c_int, [C.POINTER(GaugePlan), _F, _I32, _P, _P, _P, _I64, _P, _P, _SZ, _P]),
     "l2hmc_gauge_trajectory": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                          _SZ, _P]),

@@ -96,7 +96,7 @@ extern "C" int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
 extern "C" const char* l2hmc_last_error(void) { return g_err; }
 
 extern "C" int l2hmc_profile_begin(int32_t kernel_class) {
-  L2HMC_REQUIRE(kernel_class >= kProfNone && kernel_class <= kProfFused, "profile_begin: unknown class %d",
+  L2HMC_REQUIRE(kernel_class >= kProfNone && kernel_class <= kProfLast, "profile_begin: unknown class %d",
                 kernel_class);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_cls.store(kernel_class, std::memory_order_relaxed);

@@ -71,7 +71,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // Optional per-kernel-class timing with HIP events on the launch stream
 // (l2hmc_profile_begin/_end; used by bench.py's roofline pass, off otherwise).
-enum ProfClass { kProfNone = 0, kProfGemmL1 = 1, kProfGemmL2 = 2, kProfHeads = 3, kProfU1 = 4, kProfFused = 5 };
+enum ProfClass { kProfNone = 0, kProfGemmL1 = 1, kProfGemmL2 = 2, kProfHeads = 3, kProfU1 = 4, kProfFused = 5,
+                 kProfConvFront = 6, kProfSmall = 7, kProfLast = kProfSmall };
 void prof_before(int cls, hipStream_t stream);
 void prof_after(int cls, hipStream_t stream);
 

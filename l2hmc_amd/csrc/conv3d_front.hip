@@ -260,12 +260,14 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
+  prof_before(kProfConvFront, stream);
   if (a.F == 8 && a.T == 8 && a.X == 8)
     hipLaunchKernelGGL((conv3d_front_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
   else if (a.F == 16 && a.T == 16 && a.X == 16)
     hipLaunchKernelGGL((conv3d_front_kernel<16, 16>), grid, dim3(kConvThreads), lds, stream, a);
   else
     hipLaunchKernelGGL((conv3d_front_kernel<0, 0>), grid, dim3(kConvThreads), lds, stream, a);
+  prof_after(kProfConvFront, stream);
   L2HMC_CHECK_LAUNCH("conv3d_front");
   return L2HMC_OK;
 }

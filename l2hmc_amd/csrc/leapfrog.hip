@@ -546,6 +546,11 @@ extern "C" size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t row
   return carve_gauge_ws(plan, rows, nullptr).bytes;
 }
 
+extern "C" int l2hmc_gauge_plan_fused(const l2hmc_gauge_plan* plan) {
+  if (int e = check_plan(plan)) return -e;
+  return use_fused(plan) ? 1 : 0;
+}
+
 extern "C" int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, int32_t step, float* x, float* v,
                                     const int32_t* dir, int64_t rows, float* logdet, void* ws, size_t ws_bytes,
                                     l2hmc_stream_t stream) {

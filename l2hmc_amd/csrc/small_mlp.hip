@@ -470,7 +470,9 @@ static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) 
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
+  prof_before(kProfSmall, st);
   hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_>), grid, dim3(kSmallThreads), lds, st, a);
+  prof_after(kProfSmall, st);
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;
 }

@@ -23,6 +23,32 @@ def test_launcher_decision():
     assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
 
 
+def test_chain_partition_of_every_config():
+    """contiguous blocks of B / world_size chains; configs 4 and 5 are 8192 and 16384 chains over the
+    node (1024 and 2048 per GPU at 8 GPUs), config 3 weak-scales 2048 per GPU or strong-scales its 2048."""
+    for cfg, glob, per in ((4, 8192, 1024), (5, 16384, 2048)):
+        blocks = [bench.rank_chains(cfg, 8, r, "strong") for r in range(8)]
+        assert [b[:2] for b in blocks] == [(r * per, (r + 1) * per) for r in range(8)]
+        assert all(b[2] == glob for b in blocks)
+        assert bench.rank_chains(cfg, 1, 0, "strong") == (0, glob, glob)           # one GPU: the whole batch
+        assert bench.rank_chains(cfg, 1, 0, "weak") == (0, per, per)               # one GPU: one shard of the 8
+    assert [bench.rank_chains(3, 4, r, "weak")[:2] for r in range(4)] == [(2048 * r, 2048 * (r + 1)) for r in range(4)]
+    assert bench.rank_chains(3, 4, 0, "weak")[2] == 8192
+    assert [bench.rank_chains(3, 4, r, "strong") for r in range(4)] == [(512 * r, 512 * (r + 1), 2048) for r in range(4)]
+    # a batch that does not divide: remainder on the first ranks, nothing lost, nothing doubled
+    cuts = [bench.rank_chains(3, 3, r, "strong")[:2] for r in range(3)]
+    assert cuts == [(0, 683), (683, 1366), (1366, 2048)]
+    assert bench.CONFIGS[4]["scaling"] == bench.CONFIGS[5]["scaling"] == "strong" and bench.CONFIGS[3]["scaling"] == "weak"
+
+
+def test_algorithmic_flops_match_the_survey_sizes_table():
+    """SURVEY.md 8, sizes table: FLOPs per chain-LF step = 8 x MACs per net call."""
+    assert 8 * bench.config_macs(1)[0] == 1760 and 8 * bench.config_macs(2)[0] == 24800
+    assert 8 * bench.config_macs(3)[0] == 4726784
+    assert 8 * bench.config_macs(4)[0] == 35930112
+    assert 8 * bench.config_macs(5)[0] == 1208090624
+
+
 def _run(args, extra_env=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(extra_env or {})
@@ -37,6 +63,17 @@ def test_bare_invocation_starts_two_ranks_over_gloo():
     assert len(lines) == 1                                    # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["max_elapsed_s"] >= 0.02
+
+
+def test_config4_partition_over_two_ranks():
+    """`--config 4 --gpus 2`: the 8192 chains of BASELINE.json configs[3] in two contiguous shards, through the
+    real launcher; config 3 with `--scaling strong` cuts its 2048."""
+    for args, want, glob in ((["--config", "4"], [[0, 4096], [4096, 8192]], 8192),
+                             (["--config", "3", "--scaling", "strong"], [[0, 1024], [1024, 2048]], 2048)):
+        r = _run(["--gpus", "2", "--rendezvous-only", *args])
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert out["chains"] == want and out["global_batch"] == glob and out["ranks_seen"] == 2, out
 
 
 def test_failing_rank_gives_nonzero_exit():

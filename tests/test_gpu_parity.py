@@ -25,10 +25,10 @@ abs deviation relative to the tensor's own scale (>= 1).
         extreme value of a heavy-tailed distribution on both sides: the ratio of
         the two maxima scatters (worst single sample 4.61 among 96 32-chain
         trajectories, 3.62 among 32 128-chain ones, typical 0.7-1.3; the
-        libm-exp/tanh diagnostic build has the same means) -> MAX_RATIO = 6 is
+        libm-exp/tanh diagnostic build has the same means) -> MAX_RATIO = 5 is
         an extreme-value allowance, not a precision one;
       - accept probability: a few chains per sample have p != 0, so the max
-        ratio scatters most (typical <= 2.2)          -> P_RATIO = 6.
+        ratio scatters most (worst 2.74, typical <= 2.2) -> P_RATIO = 3.5.
     Both apply only above the absolute bars (TOL_OP max, TOL_OP / 3 RMS, TOL_P):
     on benign dynamics (small step, near-cold start) the whole trajectory is
     held to TOL_OP outright (test_trajectory_within_1e5_on_benign_dynamics).
@@ -46,7 +46,8 @@ pytestmark = pytest.mark.gpu
 
 TOL_OP = 1e-5
 TOL_P = 2e-5
-MAX_RATIO, Q999_RATIO, RMS_RATIO, P_RATIO = 6.0, 2.5, 1.6, 6.0     # measured allowances over the fp32 oracle's own error
+MAX_RATIO, Q999_RATIO, RMS_RATIO, P_RATIO = 5.0, 2.5, 1.6, 3.5     # measured allowances over the fp32 oracle's own error
+FUSED_VS_LAYERED_X, FUSED_VS_LAYERED_P = 5e-5, 1e-4       # full-size cfg 3, fused against layered (see the test)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 H_REG = H.REGIMES
 
@@ -308,10 +309,11 @@ def test_hmc_mode_is_plain_leapfrog(la):
     xo, vo, p, sld = dyn.transition_kernel(x, beta, forward=True, momentum=v0f, return_logdet=True)
     want = orc.transition_kernel(x, beta, v0f, forward=True)
     assert H.relerr(np_(xo), want[0]) < TOL_OP and H.relerr(np_(vo), want[1]) < TOL_OP
-    assert torch.all(sld == 0) and np.abs(np_(p) - want[2]).max() < 1e-4
+    assert torch.all(sld == 0) and np.abs(np_(p) - want[2]).max() < TOL_P, np.abs(np_(p) - want[2]).max()
     got = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
     w = orc.apply_transition(x, beta, v0f, v0b, coin, u)
-    assert H.relerr(np_(got[0]), w[0]) < TOL_OP and np.abs(np_(got[2]) - w[2]).max() < 1e-4
+    assert H.relerr(np_(got[0]), w[0]) < TOL_OP and np.abs(np_(got[2]) - w[2]).max() < TOL_P, \
+        np.abs(np_(got[2]) - w[2]).max()
 
 
 def test_sub_update_methods_on_materialised_stq(la):
@@ -762,7 +764,11 @@ def test_full_size_properties_cfg3(la):
     assert torch.equal(x1, x1b) and torch.equal(p1, p1b)
     dyn.fused = False
     x1c, v1c, p1c, ld1c = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
-    assert H.relerr(np_(x1c), np_(x1)) < 5e-5 and np.abs(np_(p1c) - np_(p1)).max() < 1e-4
+    # two fp32 summation orders of the same 10 mildly chaotic steps over 2048 chains (measured on the box:
+    # profiles/r03_gate_envelope.txt)
+    dx_fl, dp_fl = H.relerr(np_(x1c), np_(x1)), np.abs(np_(p1c) - np_(p1)).max()
+    print(f"cfg3 full size, fused vs layered: x {dx_fl:.2e}  p {dp_fl:.2e}")
+    assert dx_fl < FUSED_VS_LAYERED_X and dp_fl < FUSED_VS_LAYERED_P, (dx_fl, dp_fl)
     dyn.fused = True
     # (3) first 64 chains agree with the oracle; p in [0, 1]
     orc = H.gauge_oracle(T, X, N, eps, xp, vp)

@@ -7,7 +7,7 @@ for x, v, the accumulated log-det (max norm and RMS, both relative to max(1, max
 trajectory, the accept probability -- and prints the ratio e_hip / e_f32.  The parity tests' allowance for
 chaotic trajectories (tests/test_gpu_parity.py: assert_fp32_equivalent) is set from this table.
 
-    python tools/error_ratio.py [cfg3|cfg3conv|cfg4] [--lib path/to/alternative/libl2hmc_hip.so]
+    python tools/error_ratio.py [cfg3|cfg3conv|cfg4|cfg5] [--lib path/to/alternative/libl2hmc_hip.so]
 
 The --lib switch loads a diagnostic build (tools/build_exact.sh: libm expf/tanhf instead of the v_exp_f32 /
 v_rcp_f32 forms) to show how much of the error the hardware transcendental forms account for.
@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()
-ap.add_argument("config", nargs="?", default="cfg3", choices=["cfg3", "cfg3conv", "cfg4"])
+ap.add_argument("config", nargs="?", default="cfg3", choices=["cfg3", "cfg3conv", "cfg4", "cfg5"])
 ap.add_argument("--lib", default=None)
 ap.add_argument("--chains", type=int, default=128)
 ap.add_argument("--seeds", type=int, default=4)
@@ -39,7 +39,8 @@ CFG = {  # L, N, eps, beta, arch   (SURVEY.md 8d synthetic inputs)
     "cfg3": (8, 10, 0.25, 2.0, "generic"),
     "cfg3conv": (8, 10, 0.25, 2.0, "conv3D"),
     "cfg4": (16, 15, 0.2, 3.0, "conv3D"),
-}
+    "cfg5": (32, 25, 0.1, 4.0, "generic"),      # D = 2048, H = 8192: run with --chains 4 --seeds 2 (the NumPy oracles
+}                                               # stream 2 x 604 MB of weights per network call)
 
 
 def rel(got, want):
@@ -73,7 +74,9 @@ def main():
         o64 = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch)
         o32 = H.gauge_oracle(L, L, N, eps, xp, vp, arch=arch, dtype=np.float32)
         dyn = H.gauge_hip(L, L, N, eps, xp, vp, o64.mask, B, arch=arch)
-        for fused in (True, False):
+        import ctypes
+        has_fused = _lib.lib().l2hmc_gauge_plan_fused(ctypes.byref(dyn._plan())) == 1
+        for fused in ((True, False) if has_fused else (False,)):     # shapes without a whole-trajectory kernel: layered only
             dyn.fused = fused
             path = "fused" if fused else "layered"
             # accumulate over seeds and directions: per step, per quantity -> lists of (e_hip, e_f32)
