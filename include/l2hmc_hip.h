@@ -185,6 +185,10 @@ int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const flo
 #define L2HMC_PLAN_SELECTED_ONLY 4   /* l2hmc_gauge_mcmc_step integrates only the direction each chain's coin picks:
                                       * same draws, same outputs as the default whenever the other direction is
                                       * finite (the reference multiplies it by an exact 0), half the work */
+#define L2HMC_PLAN_RECOMPUTE 8       /* layer-by-layer path: form every first-layer product anew, as the reference's graph
+                                      * does, instead of keeping the ones a leapfrog step repeats (XNet's product with
+                                      * the momentum across the two position sub-updates; VNet's whole product from the
+                                      * end of one step to the start of the next).  Same bits either way; diagnostic */
 typedef struct l2hmc_gauge_plan {
   int32_t T, X;            /* lattice extents; D = 2*T*X */
   int32_t num_steps;       /* N_LF */

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
-PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY = 1, 2, 4
+PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY, PLAN_RECOMPUTE = 1, 2, 4, 8
 GRAD_BUCKET_REST = 6
 BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 

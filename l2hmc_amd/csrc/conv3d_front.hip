@@ -26,7 +26,7 @@ constexpr int kConvThreads = 256;
 template <int FT, int LT>
 __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int which = blockIdx.y;                   // 0: first input, 1: second input
+  const int which = p.only ? p.only - 1 : blockIdx.y;   // 0: first input, 1: second input
   const int T = LT ? LT : p.T, X = LT ? LT : p.X, F = FT ? FT : p.F, F2 = 2 * F;
   const int D = 2 * T * X;
   const int TP = T + 2, XP = X + 2;               // conv1 halo (pad 1 / 1)
@@ -249,7 +249,8 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
                                       (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
-  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
+  L2HMC_REQUIRE(a.only >= 0 && a.only <= 2, "conv3d front-end: bad input selector %d", a.only);
+  const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), a.only ? 1 : 2);
   static DeviceOnce attr_once;
   if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_kernel<8, 8>),

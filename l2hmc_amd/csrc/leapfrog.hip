@@ -182,8 +182,19 @@ __global__ __launch_bounds__(256) void accept_selected_kernel(const float* __res
 struct GaugeWs {
   float* h1; float* h2; float* g; float* ld_part; float* mask_inv; float* fa; float* fb;
   float* act0; float* kin0; float* act1; float* kin1;
+  float* pre_v; float* pre_x;      // kept first-layer products [rows][H] (NULL when the plan recomputes them)
   size_t bytes;
 };
+
+// Recurring first-layer products of a leapfrog step (gauge_dynamics.py:412-483 evaluates every one of them anew):
+//   * the two position sub-updates of a step call XNet on (v, m.x) and (v, m_inv.x) with the SAME v: the momentum
+//     half of the first-layer product (and, for ConvNet3D, the conv stack of v) is formed once;
+//   * the momentum update that ends step s and the one that starts step s + 1 call VNet on the SAME (x, force(x)) --
+//     only the time input differs, and that enters after the product: force, conv stacks and the whole first-layer
+//     product of the second call are the first call's.
+// The kept values are the fp32 accumulators of an ascending-k fma chain, so the results are bit-identical to the
+// recomputing path (L2HMC_PLAN_RECOMPUTE; tests/test_gpu_parity.py::test_kept_products_equal_recomputed).
+enum NetCarry { kCarryNone = 0, kCarryVSave, kCarryVUse, kCarryXFirst, kCarrySecond };
 
 static bool use_fused(const l2hmc_gauge_plan* p) {
   return !(p->flags & L2HMC_PLAN_LAYERED) && fused_plan_supported(p);
@@ -214,6 +225,10 @@ static GaugeWs carve_gauge_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
   w.kin0 = take(rows);
   w.act1 = take(rows);
   w.kin1 = take(rows);
+  const bool keep = !p->hmc && !(p->flags & L2HMC_PLAN_RECOMPUTE) && dense_net_tileable(&p->xnet) &&
+                    dense_net_tileable(&p->vnet);
+  w.pre_v = keep ? take((size_t)rows * p->vnet.H) : nullptr;
+  w.pre_x = keep ? take((size_t)rows * p->xnet.H) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -255,7 +270,15 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
                       const float* b, const float* cm_f, const float* cm_b, const int* dir,
                       const float tcs[4], int64_t rows, int mode, float* x, float* v, const float* g,
                       const float* keep_f, const float* keep_b, float eps, const GaugeWs& w, int ncb,
-                      hipStream_t stream) {
+                      hipStream_t stream, int carry = kCarryNone) {
+  if (carry == kCarryVUse) {
+    // same (x, force) as the call that kept the product: only bias + time term + relu remain of the first layer
+    L1FinishArgs f{};
+    f.pre = w.pre_v; f.out = w.h1; f.N = net->H; f.rows = rows;
+    f.bias = net->b1; f.wt0 = net->wt; f.wt1 = net->wt + net->H;
+    f.dir = dir; f.tc_f = tcs[0]; f.ts_f = tcs[1]; f.tc_b = tcs[2]; f.ts_b = tcs[3];
+    if (int e = launch_l1_finish(f, stream)) return e;
+  } else {
   if (plan->flags & L2HMC_PLAN_CONV3D) {
     // conv_net.py:251-262: both inputs through their conv stacks, then the dense trunk on the features
     const l2hmc_conv3d_front* f = (net == &plan->xnet) ? &plan->xfront : &plan->vfront;
@@ -265,6 +288,7 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
     c.w1[0] = f->w1_a; c.b1[0] = f->b1_a; c.w2[0] = f->w2_a; c.b2[0] = f->b2_a;
     c.w1[1] = f->w1_b; c.b1[1] = f->b1_b; c.w2[1] = f->w2_b; c.b2[1] = f->b2_b;
     c.out[0] = w.fa; c.out[1] = w.fb; c.ldo = net->Ka; c.rows = rows;
+    c.only = carry == kCarrySecond ? 2 : 0;       // the first input's features are still in w.fa
     if (int e = launch_conv3d_front(c, stream)) return e;
     a = w.fa; b = w.fb; cm_f = cm_b = nullptr;
   }
@@ -277,7 +301,11 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
   l1.bias = net->b1; l1.wt0 = net->wt; l1.wt1 = net->wt + net->H;
   l1.tc_f = tcs[0]; l1.ts_f = tcs[1]; l1.tc_b = tcs[2]; l1.ts_b = tcs[3];
   l1.out = w.h1; l1.ldo = net->H; l1.rows = rows;
+  if (carry == kCarryVSave) { l1.acc_out = w.pre_v; l1.k_dump = l1.K; }
+  if (carry == kCarryXFirst) { l1.acc_out = w.pre_x; l1.k_dump = net->Ka; }
+  if (carry == kCarrySecond) { l1.acc_in = w.pre_x; l1.k_begin = net->Ka; }
   if (int e = launch_gemm_relu(l1, stream)) return e;
+  }
 
   GemmReluArgs l2{};
   l2.A1 = w.h1; l2.lda1 = net->H; l2.K1 = net->H;
@@ -295,9 +323,21 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
   return launch_heads(h, stream);
 }
 
+// the kept products travel through the aligned tile loads only: every operand of a first layer 16-byte aligned
+static bool carry_possible(const l2hmc_gauge_plan* p, const float* x, const float* v, const GaugeWs& w) {
+  auto ok = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int D = 2 * p->T * p->X;
+  return w.pre_v != nullptr && (D % 4) == 0 && ok(x) && ok(v) && ok(p->masks) && ok(p->xnet.w1_t) && ok(p->vnet.w1_t) &&
+         ok(p->xnet.b1) && ok(p->vnet.b1) && ok(p->xnet.wt) && ok(p->vnet.wt) && (p->xnet.H % 4) == 0 &&
+         (p->vnet.H % 4) == 0;
+}
+
 // one augmented leapfrog step in place; log-det goes to w.ld_part (+=)
+// use_prev: the previous step of this launch kept VNet's first-layer product and the force of the current x;
+// keep_last: keep them for the next step
 static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float* x, float* v,
-                         const int* dir, int64_t rows, const GaugeWs& w, hipStream_t stream) {
+                         const int* dir, int64_t rows, const GaugeWs& w, hipStream_t stream, bool carry = false,
+                         bool use_prev = false, bool keep_last = false) {
   const int D = 2 * p->T * p->X;
   const int N = p->num_steps;
   const int sf = step, sb = N - 1 - step;   // gauge_dynamics.py:453-457
@@ -328,21 +368,24 @@ static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float*
           L2HMC_CHECK_LAUNCH("lf_update_x");
         } else {
           if (int e = net_update(p, &p->xnet, v, x, kf, kb, dir, tcs, rows, /*mode x*/ 2, x, v, nullptr, kf, kb,
-                                 p->eps, w, ncb, stream))
+                                 p->eps, w, ncb, stream, !carry ? kCarryNone : sub == 0 ? kCarryXFirst : kCarrySecond))
             return e;
         }
       }
     }
-    // momentum half-kick (:423-425 and :440-442)
-    if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, nullptr, w.g, nullptr, nullptr, stream))
-      return e;
+    // momentum half-kick (:423-425 and :440-442); w.g still holds force(x) when the previous step kept it
+    const bool reuse = half == 0 && use_prev && !p->hmc;
+    if (!reuse)
+      if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, nullptr, w.g, nullptr, nullptr, stream))
+        return e;
     if (p->hmc) {
       hipLaunchKernelGGL(lf_update_v_kernel, dim3(rgrid), dim3(256), 0, stream, v, w.g, nullptr, nullptr,
                          nullptr, p->eps, dir, 0, rows, D, v, nullptr, 0);
       L2HMC_CHECK_LAUNCH("lf_update_v");
     } else {
       if (int e = net_update(p, &p->vnet, x, w.g, nullptr, nullptr, dir, tcs, rows, /*mode v*/ 1, x, v, w.g,
-                             nullptr, nullptr, p->eps, w, ncb, stream))
+                             nullptr, nullptr, p->eps, w, ncb, stream,
+                             reuse ? kCarryVUse : (half == 1 && keep_last) ? kCarryVSave : kCarryNone))
         return e;
     }
   }
@@ -376,8 +419,11 @@ static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, f
       return e;
     if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin0, stream)) return e;
   }
+  const bool carry = carry_possible(p, x, v, w);
   for (int step = 0; step < p->num_steps; ++step)
-    if (int e = leapfrog_step(p, beta, step, x, v, dir, rows, w, stream)) return e;
+    if (int e = leapfrog_step(p, beta, step, x, v, dir, rows, w, stream, carry, carry && step > 0,
+                              carry && step + 1 < p->num_steps))
+      return e;
   if (p_accept) {
     if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, w.act1, nullptr, nullptr, nullptr, stream))
       return e;
@@ -567,7 +613,7 @@ extern "C" int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, in
   if (use_fused(plan))
     return launch_fused_trajectory(plan, beta, step, step + 1, x, v, dir, rows, x, v, logdet, 1, nullptr, s);
   if (int e = prepare_ws(plan, rows, w, s)) return e;
-  if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s)) return e;
+  if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s, carry_possible(plan, x, v, w))) return e;
   if (logdet) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, w.ld_part,
                        gauge_ncb(plan), rows, logdet, 1);

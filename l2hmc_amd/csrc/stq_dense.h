@@ -21,7 +21,21 @@ struct GemmReluArgs {
   unsigned long long* stamps;          // diagnostic builds only (-DL2HMC_STAMPS), else NULL
   int kind;                            // 0: relu layer (forward); 3: out = product where gate > 0; 4: plain product
   const float* gate; int ldg;          // kind 3: forward activations [rows][N]
+  // Recurring first-layer products (leapfrog.hip: two position sub-updates share the momentum half of the product,
+  // the momentum update at the start of a step repeats the whole product of the previous step's last one).  The
+  // product is an fp32 fma chain in ascending k, so a chain cut at a tile boundary, kept in fp32 and continued later
+  // gives the bits of the uninterrupted chain.
+  const float* acc_in; int k_begin;    // start the accumulators from acc_in [rows][N] and the k-loop at k_begin
+  float* acc_out; int k_dump;          // write the raw accumulators (no bias / relu) once k has reached k_dump
+};                                     // (both multiples of the k-tile; k_dump == K: the full product)
+
+// h1 = relu(pre + bias + t . Wt) from a saved first-layer product (the epilogue of gemm_relu_kernel<., 1> alone)
+struct L1FinishArgs {
+  const float* pre; float* out; int N; int64_t rows;
+  const float* bias; const float* wt0; const float* wt1;
+  const int* dir; float tc_f, ts_f, tc_b, ts_b;
 };
+int launch_l1_finish(const L1FinishArgs& a, hipStream_t stream);
 
 // heads: (S,T,Q) = h2 . Whd^T + bhd, then materialise or fused v/x update
 enum HeadsMode { kHeadsMaterialise = 0, kHeadsUpdateV = 1, kHeadsUpdateX = 2 };
@@ -84,6 +98,7 @@ struct ConvFrontArgs {
   int64_t rows;
   int cpw;                               // chains per workgroup (set by the launcher)
   int ldi;                               // row stride of `in` (0 = 2*T*X)
+  int only;                              // 0: both inputs; 1: the first input only; 2: the second input only
 };
 
 // backward of the front-end (training path); input `which` lives at column offset which*D of `in` / `din`

@@ -37,6 +37,13 @@ constexpr int kGemmThreads = 256;  // 4 waves
 // =====================================================================
 
 
+// bias and time term of the first layer, in ONE place: gemm_relu_kernel<., 1> and l1_finish_kernel must round alike
+__device__ __forceinline__ float l1_preact(float acc, float bj, float tc, float ts, float w0, float w1) {
+  float h = acc + bj;
+  h += tc * w0 + ts * w1;
+  return h;
+}
+
 // KIND 1: first layer (two k-contiguous sources, optional column mask, time term)
 // KIND 2: hidden layer (single source, plain bias)
 // KIND 3: backward-data through a relu layer: out = (A . Wt^T) where gate > 0, else 0   (no bias)
@@ -184,13 +191,39 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // raw accumulators <-> [rows][N] in the C layout of the 32x32 MFMA (a lane's 32-column run is 128 contiguous bytes)
+  auto acc_io = [&](const float* src, float* dst) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * WN + j * 32 + r;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (row < p.rows && col < p.N) {
+            if (src) acc[i][j][e] = src[row * p.N + col];
+            else dst[row * p.N + col] = acc[i][j][e];
+          }
+        }
+    }
+  };
+  int kt0 = 0, kt_dump = -1;
+  if constexpr (KIND == 1) {
+    if (p.acc_in) {
+      kt0 = p.k_begin / BK;
+      acc_io(p.acc_in, nullptr);
+    }
+    if (p.acc_out) kt_dump = p.k_dump / BK;
+  }
+
   const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
-  load_tile(0);
+  load_tile(kt0);
   store_tile(0);
   __syncthreads();
   L2HMC_STAMP(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
     if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
     const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + half * 4;
     const float* bs = lds + cur * STAGE + BM * LDK + (wn * WN + r) * LDK + half * 4;
@@ -208,6 +241,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (KIND == 1) {
+      if (kt + 1 == kt_dump) acc_io(nullptr, p.acc_out);   // uniform; at most once
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
@@ -229,12 +265,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
       for (int e = 0; e < 16; ++e) {
         const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (row < p.rows && cok) {
-          float h = acc[i][j][e] + bj;
+          float h;
           if (KIND == 1) {
             const int d = p.dir ? p.dir[row] : 0;
-            const float tc = d ? p.tc_b : p.tc_f;
-            const float ts = d ? p.ts_b : p.ts_f;
-            h += tc * w0 + ts * w1;
+            h = l1_preact(acc[i][j][e], bj, d ? p.tc_b : p.tc_f, d ? p.ts_b : p.ts_f, w0, w1);
+          } else {
+            h = acc[i][j][e] + bj;
           }
           if (KIND == 3) h = p.gate[row * p.ldg + col] > 0.f ? h : 0.f;
           p.out[row * p.ldo + col] = KIND <= 2 ? fmaxf(h, 0.f) : h;
@@ -244,6 +280,38 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
   }
   L2HMC_STAMP(3);
   L2HMC_STAMP_REAL(5);
+}
+
+// h1 = relu(pre + bias + t . Wt): the first layer's epilogue on a product kept from an earlier call (the momentum
+// network sees the same (x, force) at the end of one leapfrog step and at the start of the next; only t differs)
+__global__ __launch_bounds__(256) void l1_finish_kernel(L1FinishArgs p) {
+  const int n4 = p.N >> 2;
+  const int64_t total = p.rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / n4;
+    const int c = (int)(i - row * n4) * 4;
+    const int d = p.dir ? p.dir[row] : 0;
+    const float tc = d ? p.tc_b : p.tc_f, ts = d ? p.ts_b : p.ts_f;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.pre + row * p.N + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c);
+    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.wt0) {
+      w0 = *reinterpret_cast<const f32x4*>(p.wt0 + c);
+      w1 = *reinterpret_cast<const f32x4*>(p.wt1 + c);
+    }
+    f32x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = fmaxf(l1_preact(a[j], b[j], tc, ts, w0[j], w1[j]), 0.f);
+    *reinterpret_cast<f32x4*>(p.out + row * p.N + c) = h;
+  }
+}
+
+int launch_l1_finish(const L1FinishArgs& a, hipStream_t stream) {
+  L2HMC_REQUIRE(a.pre && a.out && a.bias && a.N > 0 && a.N % 4 == 0 && a.rows > 0, "l1_finish: bad arguments");
+  const int64_t total = a.rows * (a.N >> 2);
+  hipLaunchKernelGGL(l1_finish_kernel, dim3((unsigned)hmin(ceil_div(total, 256), 8192)), dim3(256), 0, stream, a);
+  L2HMC_CHECK_LAUNCH("l1_finish");
+  return L2HMC_OK;
 }
 
 // =====================================================================
@@ -477,6 +545,11 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   const bool ragged = a.K % BK != 0 || a.K1 % BK != 0 || a.lda1 % 4 != 0 || (a.A2 != nullptr && a.lda2 % 4 != 0) ||
                       !aligned16(a.A1) || (a.K1 < a.K && !aligned16(a.A2)) || !aligned16(a.Wt) ||
                       (a.cmask_f && (!aligned16(a.cmask_f) || !aligned16(a.cmask_b)));
+  L2HMC_REQUIRE(((!a.acc_in && !a.acc_out) || (!ragged && a.kind == 0)) &&
+                    (!a.acc_in || (a.k_begin % BK == 0 && a.k_begin > 0 && a.k_begin < a.K)) &&
+                    (!a.acc_out || (a.k_dump % BK == 0 && a.k_dump > 0 && a.k_dump <= a.K)),
+                "gemm: a kept first-layer product needs tile-aligned widths (k_begin=%d, k_dump=%d, K=%d)", a.k_begin,
+                a.k_dump, a.K);
   if (ragged) {
     a.ntiles = (int)ceil_div(a.N, 128);
     a.mtiles = (int)ceil_div(a.rows, 64);
@@ -501,7 +574,8 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   a.ntiles = (int)ceil_div(a.N, 128);
   // 128-row tiles once they still fill the chip (>= 2 tiles per CU), else 64-row tiles
   const int64_t t128 = ceil_div(a.rows, 128) * a.ntiles;
-  const bool first = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr;
+  const bool first = a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr || a.acc_in != nullptr ||
+                     a.acc_out != nullptr;
   const int cls = first ? kProfGemmL1 : kProfGemmL2;
   if (a.kind >= 3) {
     // backward-data products of the training path (train.hip): same tiles, different epilogue
@@ -528,7 +602,8 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   prof_before(cls, stream);
   // grids that cannot fill the chip with 64 x 128 tiles (<= 256 of them) run 64 x 64 tiles with 64-deep k-tiles:
   // half the barriers, twice the workgroups, 70 KB of LDS each => two co-resident workgroups per CU
-  const bool deep = (a.K % 64 == 0) && (a.K1 % 64 == 0) && ceil_div(a.rows, 64) * a.ntiles <= 256;
+  const bool deep = (a.K % 64 == 0) && (a.K1 % 64 == 0) && ceil_div(a.rows, 64) * a.ntiles <= 256 &&
+                    (!a.acc_in || a.k_begin % 64 == 0) && (!a.acc_out || a.k_dump % 64 == 0);
   if (t128 >= 512) {
     a.mtiles = (int)ceil_div(a.rows, 128);
     const dim3 grid(a.mtiles * a.ntiles);

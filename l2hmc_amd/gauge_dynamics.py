@@ -34,6 +34,7 @@ class GaugeDynamics:
         self.both_directions = True      # integrate fwd AND bwd like :211-218; False = selected only
         self.fused = True                # whole-trajectory kernel where the shape has one
         self.check_numerics = False      # True: raise on a non-finite trajectory like tf.check_numerics (:26-28)
+        self.recompute = False           # True: layer-by-layer path forms every first-layer product anew (diagnostic)
         for key, val in kwargs.items():
             if key != 'eps':             # :73-75
                 setattr(self, key, val)
@@ -131,7 +132,8 @@ class GaugeDynamics:
         p = _lib.GaugePlan(T=self.lattice.time_size, X=self.lattice.space_size, num_steps=self.num_steps,
                            hmc=int(bool(self.hmc)), eps=float(self.eps),
                            flags=(0 if self.fused else _lib.PLAN_LAYERED)
-                           | (0 if self.both_directions else _lib.PLAN_SELECTED_ONLY),
+                           | (0 if self.both_directions else _lib.PLAN_SELECTED_ONLY)
+                           | (_lib.PLAN_RECOMPUTE if self.recompute else 0),
                            masks=_lib.dev_ptr(self.mask, name="mask"))
         if not self.hmc:
             p.xnet = self.position_fn.pack()

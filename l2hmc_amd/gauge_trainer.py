@@ -57,6 +57,7 @@ class GaugeTrainer:
         # Default = graph mode, as the reference's sessions run; eager_variables=True = the eager branch.
         self.eager_variables = bool(eager_variables)
         self.global_step = 0
+        self.last_bucket_count = 0       # gradient groups the last step put on the wire (0: nothing to exchange)
         dev = dyn._device
         self._nets = (dyn.position_fn, dyn.momentum_fn)
         flats = [n.flat_params() for n in self._nets]

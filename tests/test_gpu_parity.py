@@ -1261,3 +1261,33 @@ def test_dynamics_call_with_library_draws_matches_oracle(la, L, arch, B, both):
     acc = got[2] > cu[B:]
     np.testing.assert_array_equal(got[3][acc & safe], got[0][acc & safe])
     np.testing.assert_array_equal(got[3][~acc & safe], x0[~acc & safe])
+
+
+# ----------------------------------------------------------------- kept first-layer products (layer-by-layer path)
+@pytest.mark.parametrize("L,arch,N,B", [(8, "generic", 4, 37), (4, "generic", 3, 70), (8, "conv3D", 3, 21),
+                                        (16, "conv3D", 3, 9), (16, "generic", 2, 130), (6, "generic", 3, 11)])
+def test_kept_products_equal_recomputed(la, L, arch, N, B):
+    """The layer-by-layer path keeps the first-layer products a leapfrog step repeats (XNet's product with the
+    momentum across the two position sub-updates, VNet's whole product -- and the force -- from the end of one step
+    to the start of the next; csrc/leapfrog.hip).  An fp32 fma chain cut at a tile boundary and continued later has
+    the bits of the uninterrupted chain: every output must EQUAL the recomputing path (L2HMC_PLAN_RECOMPUTE, the
+    reference's evaluation order, gauge_dynamics.py:412-483).  6x6 (x_dim 72: ragged tiles) has nothing to keep and
+    must simply agree with itself."""
+    mk = H.conv_weights if arch == "conv3D" else H.gauge_weights
+    xp, vp = mk(L, L, regime="mild")
+    orc = H.gauge_oracle(L, L, N, 0.15, xp, vp, arch=arch)
+    dyn = H.gauge_hip(L, L, N, 0.15, xp, vp, orc.mask, B, arch=arch)
+    dyn.fused = False
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * L * L, seed=311)
+    outs = {}
+    for rec in (False, True):
+        dyn.recompute = rec
+        o = [dyn.transition_kernel(x, 2.0, forward=fwd, momentum=v0, return_logdet=True)
+             for fwd, v0 in ((True, v0f), (False, v0b))]
+        o.append(dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u))
+        outs[rec] = [t for tup in o for t in tup]
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    # and the kept-product path is a correct trajectory (forward, against the oracle)
+    want = orc.transition_kernel(x, 2.0, v0f, forward=True)
+    assert H.relerr(np_(outs[False][0]), want[0]) < 2 * TOL_OP and H.relerr(np_(outs[False][1]), want[1]) < 2 * TOL_OP
