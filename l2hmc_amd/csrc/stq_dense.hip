@@ -321,6 +321,58 @@ int launch_l1_finish(const L1FinishArgs& a, hipStream_t stream) {
 // =====================================================================
 
 
+// per-column constants and per-element epilogue shared by the heads kernels: (S, T, Q) from the three products,
+// then materialise or the fused sub-update; returns the element's log-det contribution
+struct HeadsCol { float b_s, b_t, b_q, e_s, e_q, kf, kb; };
+__device__ __forceinline__ HeadsCol heads_col(const HeadsArgs& p, int col, bool cok) {
+  HeadsCol c;
+  c.b_s = cok ? p.bhd[col] : 0.f;
+  c.b_t = cok ? p.bhd[p.D + col] : 0.f;
+  c.b_q = cok ? p.bhd[2 * p.D + col] : 0.f;
+  c.e_s = cok ? expf(p.cs[col]) : 0.f;
+  c.e_q = cok ? expf(p.cq[col]) : 0.f;
+  c.kf = c.kb = 0.f;
+  if (p.mode == kHeadsUpdateX && cok) {
+    c.kf = p.keep_f[col];
+    c.kb = p.keep_b[col];
+  }
+  return c;
+}
+__device__ __forceinline__ float heads_element(const HeadsArgs& p, const HeadsCol& c, int64_t row, int col, float aS,
+                                               float aT, float aQ) {
+  const float S = fast_tanh(aS + c.b_s) * c.e_s;
+  const float T = aT + c.b_t;
+  float Q = aQ + c.b_q;
+  Q = (p.q_tanh ? fast_tanh(Q) : Q) * c.e_q;
+  const int64_t idx = row * p.D + col;
+  if (p.mode == kHeadsMaterialise) {
+    p.S[idx] = S;
+    p.T[idx] = T;
+    p.Q[idx] = Q;
+    return 0.f;
+  }
+  const int d = p.dir ? p.dir[row] : 0;
+  const float eps = p.eps;
+  if (p.mode == kHeadsUpdateV) {
+    // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
+    const float g = p.g[idx], v = p.v[idx];
+    const float s = (d ? -0.5f : 0.5f) * eps * S;
+    const float tq = eps * Q;
+    const float kick = 0.5f * eps * (fast_exp(tq) * g - T);
+    p.v[idx] = d ? fast_exp(s) * (v + kick) : v * fast_exp(s) - kick;
+    return s;
+  }
+  // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd)
+  const float keep = d ? c.kb : c.kf;
+  const float x = p.x[idx], v = p.v[idx];
+  const float s = (d ? -eps : eps) * S;
+  const float tq = eps * Q;
+  const float drift = eps * (fast_exp(tq) * v + T);
+  const float upd = d ? fast_exp(s) * (x - drift) : x * fast_exp(s) + drift;
+  p.x[idx] = keep * x + (1.f - keep) * upd;
+  return (1.f - keep) * s;
+}
+
 template <int BK, bool RAGGED = false>
 __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   constexpr int BM = 64, BNH = 32, NB = 3 * BNH;
@@ -451,52 +503,12 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + j * 16 + r;
     const bool cok = col < p.D;
-    const float b_s = cok ? p.bhd[col] : 0.f;
-    const float b_t = cok ? p.bhd[p.D + col] : 0.f;
-    const float b_q = cok ? p.bhd[2 * p.D + col] : 0.f;
-    const float e_s = cok ? expf(p.cs[col]) : 0.f;
-    const float e_q = cok ? expf(p.cq[col]) : 0.f;
-    float kf = 0.f, kb = 0.f;
-    if (p.mode == kHeadsUpdateX && cok) {
-      kf = p.keep_f[col];
-      kb = p.keep_b[col];
-    }
+    const HeadsCol c = heads_col(p, col, cok);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t row = m0 + wave * 16 + q * 4 + e;
       if (row >= p.rows || !cok) continue;
-      const float S = fast_tanh(acc[0][j][e] + b_s) * e_s;
-      const float T = acc[1][j][e] + b_t;
-      float Q = acc[2][j][e] + b_q;
-      Q = (p.q_tanh ? fast_tanh(Q) : Q) * e_q;
-      const int64_t idx = row * p.D + col;
-      if (p.mode == kHeadsMaterialise) {
-        p.S[idx] = S;
-        p.T[idx] = T;
-        p.Q[idx] = Q;
-      } else {
-        const int d = p.dir ? p.dir[row] : 0;
-        const float eps = p.eps;
-        if (p.mode == kHeadsUpdateV) {
-          // gauge_dynamics.py:497-506 (fwd), :549-559 (bwd)
-          const float g = p.g[idx], v = p.v[idx];
-          const float s = (d ? -0.5f : 0.5f) * eps * S;
-          const float tq = eps * Q;
-          const float kick = 0.5f * eps * (fast_exp(tq) * g - T);
-          p.v[idx] = d ? fast_exp(s) * (v + kick) : v * fast_exp(s) - kick;
-          ld[e] += s;
-        } else {
-          // gauge_dynamics.py:519-531 (fwd), :574-584 (bwd)
-          const float keep = d ? kb : kf;
-          const float x = p.x[idx], v = p.v[idx];
-          const float s = (d ? -eps : eps) * S;
-          const float tq = eps * Q;
-          const float drift = eps * (fast_exp(tq) * v + T);
-          const float upd = d ? fast_exp(s) * (x - drift) : x * fast_exp(s) + drift;
-          p.x[idx] = keep * x + (1.f - keep) * upd;
-          ld[e] += (1.f - keep) * s;
-        }
-      }
+      ld[e] += heads_element(p, c, row, col, acc[0][j][e], acc[1][j][e], acc[2][j][e]);
     }
   }
   if (p.mode != kHeadsMaterialise && p.ld_part) {
@@ -510,6 +522,126 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   }
   L2HMC_STAMP(3);
   L2HMC_STAMP_REAL(5);
+}
+
+// =====================================================================
+// heads for grids that fill the chip (cfg 5: 4096 rows x 2048 columns): 128 rows x 64 output columns x 3 heads per
+// workgroup on 32x32x2 MFMAs.  Wave (wm, wn) owns 64 rows x 32 columns of ALL THREE heads (S, T, Q of an element
+// still share a lane): per 8 k it reads 2 + 3 fragments for 24 MFMAs of 64 cycles -- 0.10 ds_read_b128 per 1024
+// multiply-adds against 0.29 in heads_kernel (7 reads per 24 MFMAs of 32 cycles), which is what held that kernel
+// at 0.73 of the MFMA rate where the same-shape hidden layer reaches 0.86.  k-tiles of 16 (row stride 20 floats:
+// the two 16-lane groups of a ds_read_b128 hit 16 distinct 4-bank slots) keep the double buffer at 51 KB, so two
+// workgroups share a CU with independent barriers.
+// =====================================================================
+__global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
+  constexpr int BM = 128, BNH = 64, NB = 3 * BNH, BK = 16;
+  constexpr int CPR = BK / 4, LDK = BK + 4;
+  constexpr int A_CH = BM * CPR / kGemmThreads;      // 2
+  constexpr int B_CH = NB * CPR / kGemmThreads;      // 3
+  constexpr int STAGE = (BM + NB) * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
+  const int64_t m0 = (int64_t)mt_id * BM;
+  const int n0 = nt_id * BNH;
+
+  // unconditional, clamped tile loads (rows past the end repeat the last row: their products are never stored)
+  const float* a_src[A_CH];
+  int a_off[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    const int row = c / CPR, kc = (c % CPR) * 4;
+    const int64_t g = (m0 + row) < p.rows ? m0 + row : p.rows - 1;
+    a_src[i] = p.A + g * p.lda + kc;
+    a_off[i] = row * LDK + kc;
+  }
+  const float* b_src[B_CH];
+  int b_off[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + i * kGemmThreads;
+    const int row = c / CPR, kc = (c % CPR) * 4;     // row = head * 64 + nn
+    const int hd = row >> 6, nn = row & 63;
+    const int col = (n0 + nn) < p.D ? n0 + nn : p.D - 1;
+    b_src[i] = p.Wt + ((int64_t)hd * p.D + col) * p.K + kc;
+    b_off[i] = (BM + row) * LDK + kc;
+  }
+  f32x4 ra[A_CH], rb[B_CH];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * BK);
+  };
+  auto store_tile = [&](int buf) {
+    float* st = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<f32x4*>(st + a_off[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<f32x4*>(st + b_off[i]) = rb[i];
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][h][e] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* as = lds + cur * STAGE + (wm * 64 + r) * LDK + half * 4;
+    const float* bs = lds + cur * STAGE + (BM + wn * 32 + r) * LDK + half * 4;
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      f32x4 af[2], bf[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + kq * 8);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * BNH * LDK + kq * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int h = 0; h < 3; ++h)
+            acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[h][e], acc[i][h], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  const int col = n0 + wn * 32 + r;
+  const bool cok = col < p.D;
+  const HeadsCol c = heads_col(p, col, cok);
+  const int slot = (n0 >> 5) + wn;                   // this wave's 32-column log-det slot (ncb = ceil(D / 32))
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      float ld = 0.f;
+      if (row < p.rows && cok) ld = heads_element(p, c, row, col, acc[i][0][e], acc[i][1][e], acc[i][2][e]);
+      if (p.mode != kHeadsMaterialise && p.ld_part) {
+        const float t = wave_half_sums(ld);            // lanes 31 / 63 hold the sums over the 32 columns of a half
+        if (r == 31 && row < p.rows) p.ld_part[row * p.ncb + slot] += t;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------
@@ -643,6 +775,17 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
 #ifdef L2HMC_STAMPS
   a.stamps = g_stamp_cls == 3 ? g_stamp_buf : nullptr;
 #endif
+  // grids of at least two 128 x 64 tiles per CU: the 32x32x2 form (fewer fragment reads per MFMA)
+  if (a.K % 16 == 0 && a.D % 64 == 0 && ceil_div(a.rows, 128) * (a.D / 64) >= 512 &&
+      (a.ld_part == nullptr || a.ncb == a.D / 32)) {
+    a.mtiles = (int)ceil_div(a.rows, 128);
+    a.ntiles = a.D / 64;
+    prof_before(kProfHeads, stream);
+    hipLaunchKernelGGL(heads32_kernel, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+    prof_after(kProfHeads, stream);
+    L2HMC_CHECK_LAUNCH("heads32");
+    return L2HMC_OK;
+  }
   a.mtiles = (int)ceil_div(a.rows, 64);
   a.ntiles = (int)ceil_div(a.D, 32);
   L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);

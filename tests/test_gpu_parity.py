@@ -141,7 +141,8 @@ def test_golden_u1(la):
 @pytest.mark.parametrize("regime", ["init", "stress"])
 @pytest.mark.parametrize("D,rows", [(128, 100), (128, 1), (32, 65), (512, 70),
                                     (128, 5003),        # 64 x 128 tiles with 32-deep k-tiles (grid > 256 workgroups)
-                                    (128, 16411)])      # >= 512 tiles of 128 x 128: the large-grid instantiation
+                                    (128, 16411),       # >= 512 tiles of 128 x 128: the large-grid instantiation
+                                    (128, 32771)])      # >= 512 tiles of 128 x 64 x 3 heads: heads32_kernel (32x32x2 form)
 def test_stq_dense_matches_generic_net(la, regime, D, rows):
     rng = np.random.default_rng(5)
     p = onets.init_generic_net(np.random.default_rng(106), D, 4 * D, 2., **H.REGIMES[regime])
@@ -227,6 +228,21 @@ CASES = [  # T, X, N, eps, beta, B, regime, fused
     (4, 4, 3, 0.2, 2.5, 10, "stress", True),      # D=32: no fused kernel for this shape -> layered path
     (16, 16, 2, 0.1, 3.0, 5, "init", True),       # D=512, H=2048
 ]
+
+
+def test_leapfrog_step_on_a_chip_filling_grid(la):
+    """32771 rows of the 8x8 lattice through the layer-by-layer kernels: the grid sizes at which the large-tile
+    instantiations run (gemm_relu_kernel<128, .>, heads32_kernel with its fused sub-updates and log-det partial sums),
+    ragged last tile included; every row against the oracle."""
+    T = X = 8
+    N, eps, beta, B = 4, 0.2, 2.5, 32771
+    orc, _, dyn = _pair(T, X, N, eps, B, "stress", False)
+    rng = np.random.default_rng(77)
+    x, v = rng.uniform(0, 2 * np.pi, (B, 128)), rng.standard_normal((B, 128))
+    for step, lf, olf in ((1, dyn._forward_lf, orc._forward_lf), (2, dyn._backward_lf, orc._backward_lf)):
+        x1, v1, ld = lf(x, v, beta, step)
+        ox, ov, old = olf(x.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64), beta, step)
+        assert H.relerr(np_(x1), ox) < TOL_OP and H.relerr(np_(v1), ov) < TOL_OP and H.relerr(np_(ld), old) < TOL_OP
 
 
 @pytest.mark.parametrize("T,X,N,eps,beta,B,regime,fused", CASES)
