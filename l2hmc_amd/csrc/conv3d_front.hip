@@ -288,8 +288,10 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
 // =====================================================================================
 // (latency-bound phases want resident waves: with the tap loop of phase 4 unrolled over one axis only the (8, 8)
 // instance needs 80 registers -- fully unrolled it took 242, i.e. two workgroups per CU)
-template <int FT, int LT>
-__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void conv3d_front_bwd_kernel(
+// NTHR: threads per workgroup.  The phases are chains of dependent LDS reads; at 16 x 16 / F = 16 a chain's maps take
+// 59 KB (two workgroups per CU), so that instance runs 512 threads per workgroup to have four waves per SIMD in flight.
+template <int FT, int LT, int NTHR = kConvThreads>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) void conv3d_front_bwd_kernel(
     ConvBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;
@@ -323,17 +325,17 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
 
   const float* gw1 = p.w1[which];
   const float* gw2 = p.w2[which];
-  for (int i = tid; i < 18 * F; i += kConvThreads) w1[i] = gw1[i];
-  for (int i = tid; i < F; i += kConvThreads) b1[i] = p.b1[which][i];
-  for (int i = tid; i < 4 * F * F2; i += kConvThreads) {
+  for (int i = tid; i < 18 * F; i += NTHR) w1[i] = gw1[i];
+  for (int i = tid; i < F; i += NTHR) b1[i] = p.b1[which][i];
+  for (int i = tid; i < 4 * F * F2; i += NTHR) {
     const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
     w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
   }
-  for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
+  for (int i = tid; i < F2; i += NTHR) b2[i] = p.b2[which][i];
   {
     // xin | p1 | dpre1 | G1 | G2 are contiguous and each a multiple of four floats: one 16-byte sweep clears the halos
     const int nz4 = (int)((G2 + cpw * T2P * X2P * F2) - xin) / 4;
-    for (int i = tid; i < nz4; i += kConvThreads) reinterpret_cast<f32x4*>(xin)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < nz4; i += NTHR) reinterpret_cast<f32x4*>(xin)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // this workgroup's gradient slot is read now and written at the very end: its round trip hides under the phases
   const size_t psize = (size_t)18 * F + F + (size_t)16 * F * F + F2;
@@ -348,16 +350,16 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
     return (size_t)19 * F + (size_t)16 * F * F + (ent - 19 * F - 4 * F * F2);
   };
   // entries per thread held across the kernel
-  constexpr int kSlotRegs = FT > 0 ? (18 * FT + FT + 8 * FT * FT + 2 * FT + kConvThreads - 1) / kConvThreads : 12;
+  constexpr int kSlotRegs = FT > 0 ? (18 * FT + FT + 8 * FT * FT + 2 * FT + NTHR - 1) / NTHR : 12;
   float slot_old[kSlotRegs];
 #pragma unroll
   for (int k = 0; k < kSlotRegs; ++k) {
-    const int ent = tid + k * kConvThreads;
+    const int ent = tid + k * NTHR;
     slot_old[k] = ent < nent ? part[slot_of(ent)] : 0.f;
   }
   __syncthreads();
   const float* in = p.in + which * D;
-  for (int i = tid; i < nrow * D; i += kConvThreads) {
+  for (int i = tid; i < nrow * D; i += NTHR) {
     const int c = i / D, e = i - c * D;
     const int site = e >> 1, mu = e & 1;
     const int ii = site / X, jj = site - ii * X;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   L2HMC_STAMP(1);
   // ---- phase 1: conv1 + pool1, remember the winner of each pooled cell
   const int n1 = nrow * T2 * X2 * F;
-  for (int idx = tid; idx < n1; idx += kConvThreads) {
+  for (int idx = tid; idx < n1; idx += NTHR) {
     const int f = idx % F;
     int r = idx / F;
     const int J = r % X2;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   L2HMC_STAMP(2);
   // ---- phase 2: conv2 + pool2; the surviving feature's gradient goes to its winner in G2, zeros to the other three
   const int n2 = nrow * T4 * X4 * F2;
-  for (int idx = tid; idx < n2; idx += kConvThreads) {
+  for (int idx = tid; idx < n2; idx += NTHR) {
     const int g = idx % F2;
     int r = idx / F2;
     const int J2 = r % X4;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   // ---- phase 3: transposed conv2 (dense, no winner tests): gradient of the pooled conv1 map, gated by its own relu /
   // winner, then spread over the cell's eight pre-pooling outputs in G1.  conv2 output (i2, j2) reads p1(i2 + di,
   // j2 + dj), so p1 cell (I, J) collects output (I - di, J - dj) through tap (di, dj).
-  for (int idx = tid; idx < n1; idx += kConvThreads) {
+  for (int idx = tid; idx < n1; idx += NTHR) {
     const int ch = idx % F;
     int r = idx / F;
     const int J = r % X2;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   // ---- phase 4: transposed conv1 (dense): gradient of the raw input, both link directions of a site per thread.
   // conv1 output (i, j) reads x(i + di - 1, j + dj - 1) (zero padding: no periodic wrap, as the forward); depth 0
   // sees (mu = 0, mu = 1) through (k0, k1) = w1[tap][dd = 0 | 1], depth 1 sees mu = 1 through k0.
-  for (int sidx = tid; sidx < nrow * T * X; sidx += kConvThreads) {
+  for (int sidx = tid; sidx < nrow * T * X; sidx += NTHR) {
     const int c = sidx / (T * X), site = sidx - c * (T * X);
     const int ip = site / X, jp = site - ip * X;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   //   w2 / b2: item (chain, tap, ch, 4 g) is a dense sum over the conv2 output positions (G2 holds zeros off-winner).
   {
     const int nw1 = nrow * 9 * F;
-    for (int item = tid; item < nw1; item += kConvThreads) {
+    for (int item = tid; item < nw1; item += NTHR) {
       const int f = item % F;
       int r = item / F;
       const int tap = r % 9, c = r / 9;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
       pw[c * nent + (tap * 2 + 0) * F + f] = s0;
       pw[c * nent + (tap * 2 + 1) * F + f] = s1;
     }
-    for (int item = tid; item < nrow * F; item += kConvThreads) {
+    for (int item = tid; item < nrow * F; item += NTHR) {
       const int f = item % F, c = item / F;
       float sb = 0.f;
       for (int cell = c * T2 * X2; cell < (c + 1) * T2 * X2; ++cell) sb += dpre1[cell * F + f];
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
     }
     const int g4n = F2 / 4;
     const int nw2 = nrow * 4 * F * g4n;
-    for (int item = tid; item < nw2; item += kConvThreads) {
+    for (int item = tid; item < nw2; item += NTHR) {
       const int g4 = (item % g4n) * 4;
       int r = item / g4n;
       const int ch = r % F;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
                 p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
       *reinterpret_cast<f32x4*>(pw + c * nent + 19 * F + (tap * F + ch) * F2 + g4) = s4;
     }
-    for (int item = tid; item < nrow * F2; item += kConvThreads) {
+    for (int item = tid; item < nrow * F2; item += NTHR) {
       const int g = item % F2, c = item / F2;
       float sb = 0.f;
       for (int i2 = 0; i2 < T2; ++i2)
@@ -581,14 +583,14 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3,
   L2HMC_STAMP(6);
 #pragma unroll
   for (int k = 0; k < kSlotRegs; ++k) {
-    const int ent = tid + k * kConvThreads;
+    const int ent = tid + k * NTHR;
     if (ent < nent) {
       float sum = 0.f;
       for (int c = 0; c < nrow; ++c) sum += pw[c * nent + ent];
       part[slot_of(ent)] = slot_old[k] + sum;
     }
   }
-  for (int ent = tid + kSlotRegs * kConvThreads; ent < nent; ent += kConvThreads) {     // wider filter sets
+  for (int ent = tid + kSlotRegs * NTHR; ent < nent; ent += NTHR) {     // wider filter sets
     float sum = 0.f;
     for (int c = 0; c < nrow; ++c) sum += pw[c * nent + ent];
     part[slot_of(ent)] += sum;
@@ -627,7 +629,7 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
   if (attr_once.pending()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<8, 8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<16, 16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<16, 16, 512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_front_bwd_kernel<0, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -636,7 +638,7 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
   if (a.F == 8 && a.T == 8 && a.X == 8)
     hipLaunchKernelGGL((conv3d_front_bwd_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
   else if (a.F == 16 && a.T == 16 && a.X == 16)
-    hipLaunchKernelGGL((conv3d_front_bwd_kernel<16, 16>), grid, dim3(kConvThreads), lds, stream, a);
+    hipLaunchKernelGGL((conv3d_front_bwd_kernel<16, 16, 512>), grid, dim3(512), lds, stream, a);
   else
     hipLaunchKernelGGL((conv3d_front_bwd_kernel<0, 0>), grid, dim3(kConvThreads), lds, stream, a);
   L2HMC_CHECK_LAUNCH("conv3d_front_bwd");

@@ -90,6 +90,7 @@ def _compare(tr, tm, tol=TOL_G):
     (8, 3, 0.1, 9, "mild", True),           # ... with a partly filled 16-row tile (18 rows)
     (8, 2, 0.1, 16, "mild", False),         # same widths through the layered kernels
     (16, 1, 0.1, 3, "mild", True),          # D=512, H=2048: multi-group column sums, 16 x 16 output tiles of the TN products
+    (32, 1, 0.1, 2, "mild", True),          # cfg 5's width D=2048, H=8192 (gauge_dynamics.py:169-187): 151 M weights per net
 ])
 def test_loss_gradients_match_autograd(L, N, eps, B, regime, fused):
     tr, tm, x, z, dx, dz = _setup(L, N, eps, B, regime)
