@@ -48,7 +48,28 @@ struct SmallTrajArgs {
   // utils/sampler.py:28-59 (mix by the direction bit, Metropolis-Hastings) in its epilogue
   int64_t prop_B; uint64_t seed, draw0;
   float* Lx; float* Lv; float* px; float* mh_out;
+  unsigned long long* stamps;            // diagnostic builds only (-DL2HMC_STAMPS, class 7), else NULL
 };
+
+// Per-phase cycle counters of a wave (diagnostic build only): 0 first layer (VALU), 1 hidden layer (MFMA), 2 heads
+// (MFMA + bias + store to the wave's patch), 3 patch round trip + tanh / exp(coeff), 4 target energy / gradient,
+// 5 sub-update arithmetic (exp, masks, log-det), 6 total
+#ifdef L2HMC_STAMPS
+extern unsigned long long* g_stamp_buf;      // stq_dense.hip (l2hmc_debug_set_stamps)
+extern int g_stamp_cls;
+#define ST_NOW()                                                                              \
+  ({                                                                                          \
+    unsigned long long t_;                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    t_;                                                                                       \
+  })
+#define ST_ADD(slot, t0) st[slot] += ST_NOW() - (t0)
+#else
+#define ST_NOW() 0ull
+#define ST_ADD(slot, t0) do {} while (0)
+#endif
 
 // element i of the stream l2hmc_fill_uniform / l2hmc_fill_normal writes for (seed, offset)   (capi.hip: fill_kernel)
 __device__ __forceinline__ void philox_block_at(uint64_t seed, uint64_t offset, int64_t i, uint32_t c[4]) {
@@ -71,34 +92,34 @@ __device__ __forceinline__ float philox_normal_at(uint64_t seed, uint64_t offset
 
 // =====================================================================================================
 // The trajectory kernel.  One WAVE integrates 16 chains and never exchanges anything
-// with another wave: lane (q = lane / 16, r = lane % 16) belongs to chain r of the wave.
-//   layer 1  (K = 2 dim + 2: far too thin for a matrix instruction) on the VALU: the lane evaluates the 4 * NT
-//            hidden units k(t, e) = 16 t + 4 q + e -- exactly the values it has to feed the next layer as ITS
-//            slice of the k dimension, so no transpose and no LDS row exchange exists at all;
-//   layer 2  v_mfma_f32_16x16x4_f32 with the WEIGHTS as the first operand (16 output units x 4 k) and the 16
-//            chains as the second: 16 chains x HP x HP is a dense tile with no padding beyond num_nodes -> HP;
-//            the product comes out as out[chain r][16 to + 4 q + e], again the lane's own k slice for the heads;
-//   heads    the same instruction, N = 3 dim (<= 16 per tile); S, T, Q reach the chain's four lanes through a
-//            1 KiB wave-private LDS patch (no barrier: LDS operations of one wave execute in order).
-// Weights sit in LDS in fragment order ([tile][k-step][lane]: one conflict-free ds_read_b32 per MFMA).  The
-// previous form (16 lanes per chain on the VALU, two workgroup barriers and HP broadcast LDS reads per network call)
-// spent its time in LDS issue and barriers: profiles/r02_small_traj_before_after.txt.
+// with another wave: lane (q = lane / 16, r = lane % 16) belongs to chain r of the wave; the four lanes of a
+// chain hold the same chain state.  ALL THREE layers run on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the first
+// operand (16 output units x 4 k) and the 16 chains as the second, so a product comes out as
+// out[chain r][unit 16 t + 4 q + e] in register e of tile t -- which is, as it stands, the lane's k slice for the
+// next layer (k-step s = 4 t + e takes unit 16 t + 4 q + e from lane q): no transpose, no LDS row exchange.
+//   layer 1  input vector [a | b | cos t, sin t, 1, 0] (2 MD + 4 entries: the bias rides on the constant 1), lane q
+//            supplies entry 4 s + q of k-step s: 2 steps x NT tiles for the 2-D targets.  (Round 2 evaluated this
+//            thin layer on the VALU -- 13 steps of two ds_read_b128 and 7 multiply-adds per lane and call: 19 % of the
+//            wave's cycles, profiles/r03_small_traj_stamps.txt; the matrix pipe does it in 8 instructions.)
+//   layer 2  KSH steps x NT tiles; steps whose smallest unit 16 t + e does not exist are not run (num_nodes 50: 14)
+//   heads    outputs packed [S | T | Q] by MD; the chain's values reach its four lanes by ds_bpermute_b32 (the LDS
+//            crossbar, no memory, no barrier) instead of a store / wave barrier / load round trip through a patch.
+// Both networks' fragments, biases and coefficients live in registers (one wave per SIMD: 512 per lane); LDS holds
+// the images only for the prologue.
 // =====================================================================================================
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
-// HP: hidden width padded to the 16-wide output tiles.  KS: k-steps of the hidden layer; its inputs are produced on
-// the VALU, so step s simply takes units 4 s + q (q = lane / 16): ceil(num_nodes / 4) steps.  KSH: k-steps of the heads;
-// their inputs come out of the hidden layer's MFMAs as unit 16 t + 4 q + e in register e of tile t, so step s = 4 t + e
-// takes those, and only steps whose smallest unit 16 t + e exists are run.  num_nodes 50: 13 and 14 steps instead of
-// 16 and 16 (no multiplies by the padding up to 64).
+// HP: hidden width padded to the 16-wide output tiles.  KSH: k-steps of a layer whose inputs are a previous layer's
+// MFMA outputs (unit 16 t + 4 q + e in register e of tile t => step s = 4 t + e); only steps whose smallest unit
+// 16 t + e exists are run (num_nodes 50: 14 of 16).  KS_ is unused (kept for the instantiation list).
 template <int HP, int MD, int KS_, int KSH_>
 struct MfmaNet {
-  static constexpr int NT = HP / 16, KS = KS_, KSH = KSH_, NTH = (3 * MD + 15) / 16, REC = 4 + 2 * MD;
-  static constexpr int rec = 0;                                 // [HP][REC]: b1, wt0, wt1, 0, W1a[MD], W1b[MD]
-  static constexpr int w2 = rec + HP * REC;                     // [NT][KS][64]
-  static constexpr int whd = w2 + NT * KS * 64;                 // [NTH][KSH][64]
+  static constexpr int NT = HP / 16, KSH = KSH_, NTH = (3 * MD + 15) / 16, K1 = 2 * MD + 4, KS1 = K1 / 4;
+  static constexpr int w1 = 0;                                  // [NT][KS1][64]
+  static constexpr int w2 = w1 + NT * KS1 * 64;                 // [NT][KSH][64]
+  static constexpr int whd = w2 + NT * KSH * 64;                // [NTH][KSH][64]
   static constexpr int bh = whd + NTH * KSH * 64;               // [HP]
-  static constexpr int bhd = bh + HP;                           // [NTH * 16]
+  static constexpr int bhd = bh + HP;                           // [NTH * 16]  (outputs packed [S | T | Q] by MD)
   static constexpr int es = bhd + NTH * 16;                     // [MD] (padded to 8)
   static constexpr int eq = es + 8;
   static constexpr int size = eq + 8;
@@ -108,91 +129,124 @@ template <int HP, int MD, int KS_, int KSH_>
 __device__ void load_net_mfma(const l2hmc_dense_net& n, float* L, int dim) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
   const int H = n.H, tid = threadIdx.x;
-  for (int i = tid; i < HP * V::REC; i += kSmallThreads) {
-    const int k = i / V::REC, f = i - k * V::REC;
+  for (int i = tid; i < V::NT * V::KS1 * 64; i += kSmallThreads) {
+    const int lane = i & 63, s = (i >> 6) % V::KS1, to = (i >> 6) / V::KS1;
+    const int out = 16 * to + (lane & 15), k = 4 * s + (lane >> 4);      // entry k of [a | b | cos, sin, 1, 0]
     float val = 0.f;
-    if (k < H) {
-      if (f == 0) val = n.b1[k];
-      else if (f == 1) val = n.wt[k];
-      else if (f == 2) val = n.wt[H + k];
-      else if (f >= 4 && f < 4 + MD) { if (f - 4 < dim) val = n.w1_t[(size_t)k * 2 * dim + (f - 4)]; }
-      else if (f >= 4 + MD) { if (f - 4 - MD < dim) val = n.w1_t[(size_t)k * 2 * dim + dim + (f - 4 - MD)]; }
+    if (out < H) {
+      if (k < MD) { if (k < dim) val = n.w1_t[(size_t)out * 2 * dim + k]; }
+      else if (k < 2 * MD) { if (k - MD < dim) val = n.w1_t[(size_t)out * 2 * dim + dim + (k - MD)]; }
+      else if (k == 2 * MD) val = n.wt[out];
+      else if (k == 2 * MD + 1) val = n.wt[H + out];
+      else if (k == 2 * MD + 2) val = n.b1[out];
     }
-    L[V::rec + i] = val;
+    L[V::w1 + i] = val;
   }
-  for (int i = tid; i < V::NT * V::KS * 64; i += kSmallThreads) {
-    const int lane = i & 63, s = (i >> 6) % V::KS, to = (i >> 6) / V::KS;
-    const int out = 16 * to + (lane & 15), k = 4 * s + (lane >> 4);
+  for (int i = tid; i < V::NT * V::KSH * 64; i += kSmallThreads) {
+    const int lane = i & 63, s = (i >> 6) % V::KSH, to = (i >> 6) / V::KSH;
+    const int out = 16 * to + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
     L[V::w2 + i] = (out < H && k < H) ? n.wh_t[(size_t)out * H + k] : 0.f;
   }
   for (int i = tid; i < V::NTH * V::KSH * 64; i += kSmallThreads) {
     const int lane = i & 63, s = (i >> 6) % V::KSH, th = (i >> 6) / V::KSH;
-    const int o = 16 * th + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
-    L[V::whd + i] = (o < 3 * dim && k < H) ? n.whd_t[(size_t)o * H + k] : 0.f;
+    const int o = 16 * th + (lane & 15), hd = o / MD, d = o % MD;        // output o = head * MD + component
+    const int k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+    L[V::whd + i] = (hd < 3 && d < dim && k < H) ? n.whd_t[((size_t)hd * dim + d) * H + k] : 0.f;
   }
   for (int i = tid; i < HP; i += kSmallThreads) L[V::bh + i] = i < H ? n.bh[i] : 0.f;
-  for (int i = tid; i < V::NTH * 16; i += kSmallThreads) L[V::bhd + i] = i < 3 * dim ? n.bhd[i] : 0.f;
+  for (int i = tid; i < V::NTH * 16; i += kSmallThreads) {
+    const int hd = i / MD, d = i % MD;
+    L[V::bhd + i] = (hd < 3 && d < dim) ? n.bhd[hd * dim + d] : 0.f;
+  }
   for (int i = tid; i < 8; i += kSmallThreads) {
     L[V::es + i] = i < dim ? expf(n.coeff_s[i]) : 0.f;
     L[V::eq + i] = i < dim ? expf(n.coeff_q[i]) : 0.f;
   }
 }
 
-// The lane's fragments of the hidden layer and of the heads: with one wave per SIMD the register file (512 per lane)
-// has room for both networks' (2 x (NT + NTH) x KS = 130 registers at num_nodes 50), so the matrix instructions
-// take their weights straight from registers instead of one ds_read_b32 each, every call
+// The lane's fragments, biases and coefficients of one network (num_nodes 50, x_dim 2: 8 + 56 + 14 + 16 + 4 + 4
+// registers; two networks fit the 512-register file of a lone wave many times over)
 template <int HP, int MD, int KS_, int KSH_>
 struct NetRegs {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
-  float w2[V::NT * V::KS];
+  float w1[V::NT * V::KS1];
+  float w2[V::NT * V::KSH];
   float whd[V::NTH * V::KSH];
+  float bh[V::NT * 4];                  // bias of unit 16 t + 4 q + e at [4 t + e]
+  float bhd[V::NTH * 4];                // bias of output 16 th + 4 q + e
+  float es[MD], eq[MD];
   __device__ __forceinline__ void load(const float* L, int lane) {
+    const int q = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < V::NT * V::KS; ++i) w2[i] = L[V::w2 + i * 64 + lane];
+    for (int i = 0; i < V::NT * V::KS1; ++i) w1[i] = L[V::w1 + i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < V::NT * V::KSH; ++i) w2[i] = L[V::w2 + i * 64 + lane];
 #pragma unroll
     for (int i = 0; i < V::NTH * V::KSH; ++i) whd[i] = L[V::whd + i * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < V::NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bh[4 * t + e] = L[V::bh + 16 * t + 4 * q + e];
+#pragma unroll
+    for (int t = 0; t < V::NTH; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bhd[4 * t + e] = L[V::bhd + 16 * t + 4 * q + e];
+#pragma unroll
+    for (int d = 0; d < MD; ++d) {
+      es[d] = L[V::es + d];
+      eq[d] = L[V::eq + d];
+    }
   }
 };
 
 // (S, T, Q) = net([a, b, t]) for the 16 chains of this wave; every lane returns its own chain's values.
 template <int HP, int MD, int KS_, int KSH_>
-__device__ __forceinline__ void net_eval_mfma(const float* L, const NetRegs<HP, MD, KS_, KSH_>& W, int dim, int q_tanh,
+__device__ __forceinline__ void net_eval_mfma(const NetRegs<HP, MD, KS_, KSH_>& W, int dim, int q_tanh,
                                               const float (&a)[MD], const float (&b)[MD], float tc, float ts,
-                                              int lane, float* scr, float (&S)[MD], float (&T)[MD], float (&Q)[MD]) {
+                                              int lane, float (&S)[MD], float (&T)[MD], float (&Q)[MD],
+                                              [[maybe_unused]] unsigned long long* st = nullptr) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
-  constexpr int NT = V::NT, KS = V::KS, KSH = V::KSH, NTH = V::NTH, REC = V::REC;
+  constexpr int NT = V::NT, KSH = V::KSH, NTH = V::NTH, KS1 = V::KS1;
   const int q = lane >> 4, r = lane & 15;
-  float h1[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const float* rec = L + V::rec + (4 * s + q) * REC;
-    const f32x4s r0 = *reinterpret_cast<const f32x4s*>(rec);
-    float pre = r0[0] + (tc * r0[1] + ts * r0[2]);
-#pragma unroll
-    for (int d4 = 0; d4 < 2 * MD; d4 += 4) {
-      const f32x4s w = *reinterpret_cast<const f32x4s*>(rec + 4 + d4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = d4 + j;                        // c < MD: first input, else second (zero weights beyond dim)
-        pre += (c < MD ? a[c < MD ? c : 0] : b[c >= MD ? c - MD : 0]) * w[j];
-      }
-    }
-    h1[s] = fmaxf(pre, 0.f);
-  }
+  [[maybe_unused]] unsigned long long t0 = ST_NOW();
+  // ---- layer 1: this lane's entries 4 s + q of [a | b | cos t, sin t, 1, 0]
   f32x4s acc[NT];
 #pragma unroll
   for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+  for (int s = 0; s < KS1; ++s) {
+    float e4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * s + j;           // compile-time
+      e4[j] = k < MD ? a[k < MD ? k : 0] : k < 2 * MD ? b[(k >= MD && k < 2 * MD) ? k - MD : 0]
+              : k == 2 * MD ? tc : k == 2 * MD + 1 ? ts : k == 2 * MD + 2 ? 1.f : 0.f;
+    }
+    const float in = q == 0 ? e4[0] : q == 1 ? e4[1] : q == 2 ? e4[2] : e4[3];
 #pragma unroll
     for (int to = 0; to < NT; ++to)
-      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[to * KS + s], h1[s], acc[to], 0, 0, 0);
+      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[to * KS1 + s], in, acc[to], 0, 0, 0);
+  }
+  float h1[KSH];
+#pragma unroll
+  for (int s = 0; s < KSH; ++s) h1[s] = fmaxf(acc[s >> 2][s & 3], 0.f);
+  ST_ADD(0, t0);
+  t0 = ST_NOW();
+  // ---- layer 2
+#pragma unroll
+  for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KSH; ++s)
+#pragma unroll
+    for (int to = 0; to < NT; ++to)
+      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[to * KSH + s], h1[s], acc[to], 0, 0, 0);
   float h2[KSH];
 #pragma unroll
-  for (int s = 0; s < KSH; ++s) {
-    const int to = s >> 2, e = s & 3;
-    h2[s] = fmaxf(acc[to][e] + L[V::bh + 16 * to + 4 * q + e], 0.f);
-  }
+  for (int s = 0; s < KSH; ++s) h2[s] = fmaxf(acc[s >> 2][s & 3] + W.bh[s], 0.f);
+  ST_ADD(1, t0);
+  t0 = ST_NOW();
+  // ---- heads
+  f32x4s hv[NTH];
 #pragma unroll
   for (int th = 0; th < NTH; ++th) {
     // two accumulators (even / odd k-steps): a single one would serialise on the 40-cycle dependent latency
@@ -202,24 +256,30 @@ __device__ __forceinline__ void net_eval_mfma(const float* L, const NetRegs<HP, 
       if (s & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KSH + s], h2[s], c1, 0, 0, 0);
       else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KSH + s], h2[s], c0, 0, 0, 0);
     }
-    const f32x4s bias = *reinterpret_cast<const f32x4s*>(L + V::bhd + 16 * th + 4 * q);
-    *reinterpret_cast<f32x4s*>(scr + r * (NTH * 16) + 16 * th + 4 * q) = c0 + c1 + bias;
+    const f32x4s bias = {W.bhd[4 * th], W.bhd[4 * th + 1], W.bhd[4 * th + 2], W.bhd[4 * th + 3]};
+    hv[th] = c0 + c1 + bias;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float* mine = scr + r * (NTH * 16);
+  ST_ADD(2, t0);
+  t0 = ST_NOW();
+  // output o = head * MD + d sits in register o % 4 of tile o / 16 on the lane with q = (o % 16) / 4 of this chain
+  float out[3 * MD];
+#pragma unroll
+  for (int o = 0; o < 3 * MD; ++o) {
+    const int src = 16 * ((o & 15) >> 2) + r;
+    out[o] = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(hv[o >> 4][o & 3])));
+  }
 #pragma unroll
   for (int d = 0; d < MD; ++d) {
     if (d < dim) {
-      const float s_ = mine[d], t_ = mine[dim + d], q_ = mine[2 * dim + d];
-      S[d] = fast_tanh(s_) * L[V::es + d];
-      T[d] = t_;
-      Q[d] = (q_tanh ? fast_tanh(q_) : q_) * L[V::eq + d];
+      S[d] = fast_tanh(out[d]) * W.es[d];
+      T[d] = out[MD + d];
+      Q[d] = (q_tanh ? fast_tanh(out[2 * MD + d]) : out[2 * MD + d]) * W.eq[d];
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();          // the patch is free for the next call
+#ifdef L2HMC_STAMPS
+  asm volatile("" :: "v"(S[0]), "v"(T[0]), "v"(Q[0]));
+#endif
+  ST_ADD(3, t0);
 }
 
 // Target parameters in registers (x_dim <= 2 instance, the reference's toy targets): energy_grad() re-reads
@@ -304,13 +364,19 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   float* Lv = Lx + V::size;
   float* Lt = Lv + V::size;
   float* Lm = Lt + tv.size;                       // masks [N][dim]
-  float* scr_all = Lm + ((N * dim + 3) & ~3);     // [waves][16 chains][NTH * 16]
+  float* Lts = Lm + ((N * dim + 3) & ~3);         // (cos, sin) of 2 pi step / N, [N][2]
+  float* scr_all = Lts + ((2 * N + 3) & ~3);                   // [waves][16 chains][NTH * 16]: hand-off patch of the propose epilogue
   if (!P.hmc) {
     load_net_mfma<HP, MD, KS_, KSH_>(P.xnet, Lx, dim);
     load_net_mfma<HP, MD, KS_, KSH_>(P.vnet, Lv, dim);
   }
   load_target(P.target, Lt);
   for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
+  for (int i = threadIdx.x; i < N; i += kSmallThreads) {       // utils/dynamics.py:105-110, once instead of per step
+    const float arg = 6.28318530717958647692f * (float)i / (float)N;
+    Lts[2 * i] = cosf(arg);
+    Lts[2 * i + 1] = sinf(arg);
+  }
   __syncthreads();                                // the only workgroup barrier of the kernel
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -329,6 +395,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   const float eps = P.eps;
   const float inv_temp = 1.f / P.target.temperature;
   const int isg = P.target.is_gaussian, K = P.target.K;
+  [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] const unsigned long long st_begin = ST_NOW();
 
   float x[MD], v[MD];
 #pragma unroll
@@ -346,8 +414,13 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   const bool treg = TargetRegs<MD>::kFits && K <= TargetRegs<MD>::KM;       // uniform
   if (treg) tregs.load(Lt, dim, K);
   auto target = [&](const float (&xx)[MD], float* E, float (&gg)[MD]) {
+    [[maybe_unused]] const unsigned long long tt = ST_NOW();
     if (treg) tregs.eval(dim, K, isg, inv_temp, xx, E, gg);
     else energy_grad<MD>(Lt, dim, K, isg, inv_temp, xx, E, gg);
+#ifdef L2HMC_STAMPS
+    asm volatile("" :: "v"(*E), "v"(gg[0]));
+#endif
+    ST_ADD(4, tt);
   };
   float g[MD], E0, E1;
   target(x, &E0, g);
@@ -362,8 +435,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   for (int d = 0; d < MD; ++d) S[d] = T[d] = Q[d] = 0.f;
   for (int it = 0; it < N; ++it) {
     const int step = bwd ? N - 1 - it : it;       // utils/dynamics.py:294-296
-    const float arg = 6.28318530717958647692f * (float)step / (float)N;
-    const float tc = cosf(arg), ts = sinf(arg);
+    const float tc = Lts[2 * step], ts = Lts[2 * step + 1];
     const float* m = Lm + step * dim;
     for (int half = 0; half < 2; ++half) {
       if (half == 1) {
@@ -374,7 +446,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
             const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
             bin[d] = k * x[d];
           }
-          if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Lx, Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, scr, S, T, Q);
+          if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, S, T, Q, st);
+          [[maybe_unused]] const unsigned long long tu = ST_NOW();
 #pragma unroll
           for (int d = 0; d < MD; ++d) {
             if (d < dim) {
@@ -387,10 +460,15 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
               logdet += (1.f - k) * s;
             }
           }
+#ifdef L2HMC_STAMPS
+          asm volatile("" :: "v"(x[0]), "v"(logdet));
+#endif
+          ST_ADD(5, tu);
         }
         target(x, &E1, g);
       }
-      if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Lv, Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, scr, S, T, Q);
+      if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, S, T, Q, st);
+      [[maybe_unused]] const unsigned long long tu2 = ST_NOW();
 #pragma unroll
       for (int d = 0; d < MD; ++d) {
         if (d < dim) {
@@ -401,8 +479,18 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
           logdet += s;
         }
       }
+#ifdef L2HMC_STAMPS
+      asm volatile("" :: "v"(v[0]), "v"(logdet));
+#endif
+      ST_ADD(5, tu2);
     }
   }
+#ifdef L2HMC_STAMPS
+  if (a.stamps && lane == 0) {
+    st[6] = ST_NOW() - st_begin;
+    for (int i = 0; i < 8; ++i) a.stamps[gw * 8 + i] = st[i];
+  }
+#endif
   target(x, &E1, g);
   float kin1 = 0.f;
 #pragma unroll
@@ -456,6 +544,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
 template <int HP, int MD, int KS_, int KSH_>
 static size_t small_mfma_lds(int dim, int K, int N) {
   return sizeof(float) * (2 * (size_t)MfmaNet<HP, MD, KS_, KSH_>::size + target_view(dim, K).size + ((N * dim + 3) & ~3) +
+                          (size_t)((2 * N + 3) & ~3) +
                           (size_t)(kSmallThreads / 64) * 16 * MfmaNet<HP, MD, KS_, KSH_>::NTH * 16);
 }
 
@@ -471,7 +560,13 @@ static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) 
     attr_once.done();
   }
   prof_before(kProfSmall, st);
+#ifdef L2HMC_STAMPS
+  SmallTrajArgs b = a;
+  b.stamps = g_stamp_cls == 7 ? g_stamp_buf : nullptr;
+  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_>), grid, dim3(kSmallThreads), lds, st, b);
+#else
   hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_>), grid, dim3(kSmallThreads), lds, st, a);
+#endif
   prof_after(kProfSmall, st);
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;
