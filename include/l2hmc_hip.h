@@ -406,6 +406,12 @@ int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const 
  * fill x 4 + l2hmc_small_trajectory(2B rows) + l2hmc_mix_accept(strict = 0) bit for bit.  Both trajectories of a
  * chain run in the same wave.  Outputs (each may be NULL): Lx, Lv [B][x_dim] the proposal selected by the direction
  * bit (forward iff uniform >= 0.5), px [B] its accept probability, x_out [B][x_dim] = Lx where px - u >= 0 else x. */
+/* Tuning / diagnostic knob of the toy-target kernel (no reference counterpart): its first layer runs on the matrix
+ * pipe for batches of at most one wave per SIMD (<= 16384 rows) and on the VALU for larger ones; the two forms walk
+ * the hidden layer's k in different orders and agree to rounding.  1 / 2 force the matrix / VALU form for every batch,
+ * 0 restores the choice by size. */
+int l2hmc_small_first_layer_form(int32_t form);
+
 int l2hmc_small_propose(const l2hmc_small_plan* plan, const float* x, int64_t B, uint64_t seed, uint64_t draw0,
                         float* Lx, float* Lv, float* px, float* x_out, l2hmc_stream_t stream);
 

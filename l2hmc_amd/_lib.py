@@ -112,6 +112,7 @@ _PROTOS = {
     "l2hmc_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _I64, _I64, _P]),
     "l2hmc_mog_energy_grad": (C.c_int, [C.POINTER(MogTarget), _P, _I64, _P, _P, _P]),
     "l2hmc_small_trajectory": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "l2hmc_small_first_layer_form": (C.c_int, [_I32]),
     "l2hmc_small_propose": (C.c_int, [C.POINTER(SmallPlan), _P, _I64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     "l2hmc_small_train_ws_bytes": (_SZ, [C.POINTER(SmallPlan), _I64]),
     "l2hmc_small_train_step": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _F, _F, _P, _P, _P, _P, _P, _P, _SZ,

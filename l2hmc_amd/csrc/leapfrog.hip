@@ -71,9 +71,9 @@ __global__ void reduce_parts_kernel(const float* __restrict__ part, int ncb, int
                                     float* __restrict__ out, int accumulate) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  float s = 0.f;
-  for (int c = 0; c < ncb; ++c) s += part[r * ncb + c];
-  out[r] = accumulate ? out[r] + s : s;
+  double s = 0.0;       // up to 64 slots at x_dim 2048: the slot sum itself adds no fp32 rounding
+  for (int c = 0; c < ncb; ++c) s += (double)part[r * ncb + c];
+  out[r] = accumulate ? out[r] + (float)s : (float)s;
 }
 
 // gauge_dynamics.py:592-609 from Hamiltonians
@@ -94,12 +94,13 @@ __global__ void accept_from_parts_kernel(const float* __restrict__ act0, const f
                                          float* __restrict__ p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int c = 0; c < ncb; ++c) s += ld_part[i * ncb + c];
+  double sd = 0.0;
+  for (int c = 0; c < ncb; ++c) sd += (double)ld_part[i * ncb + c];
+  const float s = (float)sd;
   if (sumlogdet) sumlogdet[i] = s;
   if (p) {
     const double dh = (double)beta * ((double)act0[i] - (double)act1[i]) +
-                      ((double)kin0[i] - (double)kin1[i]) + (double)s;
+                      ((double)kin0[i] - (double)kin1[i]) + sd;
     p[i] = accept_from_delta(dh);
   }
 }

@@ -14,6 +14,7 @@
 // (small_train.hip) keeps the earlier sixteen-lanes-per-chain VALU form of
 // small_mlp.h.
 #include "small_mlp.h"
+#include <atomic>
 
 namespace l2hmc {
 
@@ -93,31 +94,40 @@ __device__ __forceinline__ float philox_normal_at(uint64_t seed, uint64_t offset
 // =====================================================================================================
 // The trajectory kernel.  One WAVE integrates 16 chains and never exchanges anything
 // with another wave: lane (q = lane / 16, r = lane % 16) belongs to chain r of the wave; the four lanes of a
-// chain hold the same chain state.  ALL THREE layers run on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the first
-// operand (16 output units x 4 k) and the 16 chains as the second, so a product comes out as
-// out[chain r][unit 16 t + 4 q + e] in register e of tile t -- which is, as it stands, the lane's k slice for the
-// next layer (k-step s = 4 t + e takes unit 16 t + 4 q + e from lane q): no transpose, no LDS row exchange.
-//   layer 1  input vector [a | b | cos t, sin t, 1, 0] (2 MD + 4 entries: the bias rides on the constant 1), lane q
-//            supplies entry 4 s + q of k-step s: 2 steps x NT tiles for the 2-D targets.  (Round 2 evaluated this
-//            thin layer on the VALU -- 13 steps of two ds_read_b128 and 7 multiply-adds per lane and call: 19 % of the
-//            wave's cycles, profiles/r03_small_traj_stamps.txt; the matrix pipe does it in 8 instructions.)
-//   layer 2  KSH steps x NT tiles; steps whose smallest unit 16 t + e does not exist are not run (num_nodes 50: 14)
-//   heads    outputs packed [S | T | Q] by MD; the chain's values reach its four lanes by ds_bpermute_b32 (the LDS
-//            crossbar, no memory, no barrier) instead of a store / wave barrier / load round trip through a patch.
-// Both networks' fragments, biases and coefficients live in registers (one wave per SIMD: 512 per lane); LDS holds
-// the images only for the prologue.
+// chain hold the same chain state.  Matrix instructions take the WEIGHTS as first operand (16 output units x 4 k)
+// and the 16 chains as second, so a product comes out as out[chain r][row 4 q + e of the tile] in register e.
+//   layer 1  input vector [a | b | cos t, sin t, 1, 0] (2 MD + 4 entries; the bias rides on the constant 1); a lane
+//            produces exactly the hidden units it feeds layer 2 as ITS slice of the k-steps.  Two forms, the same
+//            ascending-k fma chain per unit:
+//              L1M  on the matrix pipe: lane q supplies entry 4 s1 + q of k-step s1 (2 x NT instructions); unit
+//                   16 t + 4 q + e arrives in register e of tile t and is k-step 4 t + e of layer 2 (KSH steps).  For
+//                   batches of at most one wave per SIMD, where a wave's 4 N network calls are one chain of
+//                   dependent steps (cfg 2: 512 waves on 1024 SIMDs);
+//              VALU unit 4 s + q at step s (KS steps), 8 multiply-adds per unit from an LDS record: for chip-filling
+//                   batches, where the matrix pipe is the bound (4 x NT fewer instructions per call) and another
+//                   wave's MFMAs cover this wave's VALU work.
+//            The two forms walk layer 2's k in different orders, so they agree to rounding, not bit for bit: a batch
+//            size picks one, and every entry point (propose, trajectory) picks the same for the same rows.
+//            (Round 2 had only a VALU form: 19 % of a wave's cycles at cfg 2, profiles/r03_small_traj_stamps.txt.)
+//   layer 2  k-steps x NT tiles; the product leaves unit 16 t + 4 q + e in register e of tile t -- the lane's slice
+//            for the heads (step s = 4 t + e), again without any exchange;
+//   heads    KSH steps (only steps whose smallest unit 16 t + e exists), outputs packed [S | T | Q] by MD; the chain's
+//            values reach its four lanes by ds_bpermute_b32 (LDS crossbar: no memory, no barrier) instead of round 2's
+//            store / wave barrier / load round trip through an LDS patch.
+// Both networks' fragments, biases and coefficients live in registers (one wave per SIMD: 512 per lane).
 // =====================================================================================================
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
-// HP: hidden width padded to the 16-wide output tiles.  KSH: k-steps of a layer whose inputs are a previous layer's
-// MFMA outputs (unit 16 t + 4 q + e in register e of tile t => step s = 4 t + e); only steps whose smallest unit
-// 16 t + e exists are run (num_nodes 50: 14 of 16).  KS_ is unused (kept for the instantiation list).
+// HP: hidden width padded to the 16-wide output tiles.  KS: k-steps of the hidden layer (unit 4 s + q:
+// ceil(num_nodes / 4)).  KSH: k-steps of the heads (unit 16 t + 4 q + e at step 4 t + e; only steps whose smallest
+// unit 16 t + e exists).  num_nodes 50: 13 and 14 steps instead of 16 and 16.
 template <int HP, int MD, int KS_, int KSH_>
 struct MfmaNet {
-  static constexpr int NT = HP / 16, KSH = KSH_, NTH = (3 * MD + 15) / 16, K1 = 2 * MD + 4, KS1 = K1 / 4;
-  static constexpr int w1 = 0;                                  // [NT][KS1][64]
-  static constexpr int w2 = w1 + NT * KS1 * 64;                 // [NT][KSH][64]
-  static constexpr int whd = w2 + NT * KSH * 64;                // [NTH][KSH][64]
+  static constexpr int NT = HP / 16, KS = KS_, KSH = KSH_, NTH = (3 * MD + 15) / 16, K1 = 2 * MD + 4, KS1 = K1 / 4;
+  static constexpr int rec = 0;                                 // [HP][K1]: unit u's weights for [a | b | cos, sin, 1, 0]
+  static constexpr int w1 = rec + HP * K1;                      // [NT][KS1][64]   (L1M; permuted output rows)
+  static constexpr int w2 = w1 + NT * KS1 * 64;                 // VALU form [NT][KS][64] (k = 4 s + q); L1M [NT][KSH][64]
+  static constexpr int whd = w2 + NT * (KSH > KS ? KSH : KS) * 64;   // [NTH][KSH][64]
   static constexpr int bh = whd + NTH * KSH * 64;               // [HP]
   static constexpr int bhd = bh + HP;                           // [NTH * 16]  (outputs packed [S | T | Q] by MD)
   static constexpr int es = bhd + NTH * 16;                     // [MD] (padded to 8)
@@ -125,26 +135,37 @@ struct MfmaNet {
   static constexpr int size = eq + 8;
 };
 
-template <int HP, int MD, int KS_, int KSH_>
+// weight of hidden unit `u` for entry k of the first layer's input vector [a | b | cos t, sin t, 1, 0]
+template <int MD>
+__device__ __forceinline__ float l1_weight(const l2hmc_dense_net& n, int dim, int u, int k) {
+  if (u >= n.H) return 0.f;
+  if (k < MD) return k < dim ? n.w1_t[(size_t)u * 2 * dim + k] : 0.f;
+  if (k < 2 * MD) return k - MD < dim ? n.w1_t[(size_t)u * 2 * dim + dim + (k - MD)] : 0.f;
+  if (k == 2 * MD) return n.wt[u];
+  if (k == 2 * MD + 1) return n.wt[n.H + u];
+  if (k == 2 * MD + 2) return n.b1[u];
+  return 0.f;
+}
+
+// (the image is built by every workgroup in its prologue, which is part of a latency-bound launch: only the
+//  first-layer form that will run is filled)
+template <int HP, int MD, int KS_, int KSH_, bool L1M>
 __device__ void load_net_mfma(const l2hmc_dense_net& n, float* L, int dim) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
   const int H = n.H, tid = threadIdx.x;
-  for (int i = tid; i < V::NT * V::KS1 * 64; i += kSmallThreads) {
-    const int lane = i & 63, s = (i >> 6) % V::KS1, to = (i >> 6) / V::KS1;
-    const int out = 16 * to + (lane & 15), k = 4 * s + (lane >> 4);      // entry k of [a | b | cos, sin, 1, 0]
-    float val = 0.f;
-    if (out < H) {
-      if (k < MD) { if (k < dim) val = n.w1_t[(size_t)out * 2 * dim + k]; }
-      else if (k < 2 * MD) { if (k - MD < dim) val = n.w1_t[(size_t)out * 2 * dim + dim + (k - MD)]; }
-      else if (k == 2 * MD) val = n.wt[out];
-      else if (k == 2 * MD + 1) val = n.wt[H + out];
-      else if (k == 2 * MD + 2) val = n.b1[out];
+  if constexpr (!L1M) {
+    for (int i = tid; i < HP * V::K1; i += kSmallThreads) L[V::rec + i] = l1_weight<MD>(n, dim, i / V::K1, i % V::K1);
+  } else {
+    for (int i = tid; i < V::NT * V::KS1 * 64; i += kSmallThreads) {
+      const int lane = i & 63, s = (i >> 6) % V::KS1, to = (i >> 6) / V::KS1;
+      L[V::w1 + i] = l1_weight<MD>(n, dim, 16 * to + (lane & 15), 4 * s + (lane >> 4));
     }
-    L[V::w1 + i] = val;
   }
-  for (int i = tid; i < V::NT * V::KSH * 64; i += kSmallThreads) {
-    const int lane = i & 63, s = (i >> 6) % V::KSH, to = (i >> 6) / V::KSH;
-    const int out = 16 * to + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+  constexpr int K2 = L1M ? V::KSH : V::KS;         // k-steps of the hidden layer in this form
+  for (int i = tid; i < V::NT * K2 * 64; i += kSmallThreads) {
+    const int lane = i & 63, s = (i >> 6) % K2, to = (i >> 6) / K2;
+    const int out = 16 * to + (lane & 15);
+    const int k = L1M ? 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3) : 4 * s + (lane >> 4);
     L[V::w2 + i] = (out < H && k < H) ? n.wh_t[(size_t)out * H + k] : 0.f;
   }
   for (int i = tid; i < V::NTH * V::KSH * 64; i += kSmallThreads) {
@@ -164,85 +185,115 @@ __device__ void load_net_mfma(const l2hmc_dense_net& n, float* L, int dim) {
   }
 }
 
-// The lane's fragments, biases and coefficients of one network (num_nodes 50, x_dim 2: 8 + 56 + 14 + 16 + 4 + 4
-// registers; two networks fit the 512-register file of a lone wave many times over)
-template <int HP, int MD, int KS_, int KSH_>
+// The lane's weight fragments of one network in registers (num_nodes 50, x_dim 2: 8 + 52 + 14; both networks: 148 of
+// the lone wave's 512): the matrix instructions take their weights straight from registers.  Biases and coefficients:
+// in registers in the latency form (L1M: one wave per SIMD by design; 101 -> 92 us per cfg-2 propose), in LDS in the
+// throughput form (in registers they pushed it past 256, i.e. from two waves per SIMD to one: 0.57 -> 0.81 ms at
+// 65536 chains)
+template <int HP, int MD, int KS_, int KSH_, bool L1M>
 struct NetRegs {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
-  float w1[V::NT * V::KS1];
-  float w2[V::NT * V::KSH];
+  float w1[L1M ? V::NT * V::KS1 : 1];
+  static constexpr int K2 = L1M ? V::KSH : V::KS;
+  float w2[V::NT * K2];
   float whd[V::NTH * V::KSH];
-  float bh[V::NT * 4];                  // bias of unit 16 t + 4 q + e at [4 t + e]
-  float bhd[V::NTH * 4];                // bias of output 16 th + 4 q + e
-  float es[MD], eq[MD];
+  float bh[L1M ? V::KSH : 1];           // L1M: bias of unit 16 t + 4 q + e at [4 t + e]
+  float bhd[L1M ? V::NTH * 4 : 1];      //      bias of output 16 th + 4 q + e
+  float es[L1M ? MD : 1], eq[L1M ? MD : 1];
   __device__ __forceinline__ void load(const float* L, int lane) {
-    const int q = lane >> 4;
+    if constexpr (L1M) {
+      const int q = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < V::NT * V::KS1; ++i) w1[i] = L[V::w1 + i * 64 + lane];
+      for (int s = 0; s < V::KSH; ++s) bh[s] = L[V::bh + 16 * (s >> 2) + 4 * q + (s & 3)];
 #pragma unroll
-    for (int i = 0; i < V::NT * V::KSH; ++i) w2[i] = L[V::w2 + i * 64 + lane];
+      for (int t = 0; t < V::NTH; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bhd[4 * t + e] = L[V::bhd + 16 * t + 4 * q + e];
+#pragma unroll
+      for (int d = 0; d < MD; ++d) {
+        es[d] = L[V::es + d];
+        eq[d] = L[V::eq + d];
+      }
+#pragma unroll
+      for (int i = 0; i < V::NT * V::KS1; ++i) w1[i] = L[V::w1 + i * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < V::NT * K2; ++i) w2[i] = L[V::w2 + i * 64 + lane];
 #pragma unroll
     for (int i = 0; i < V::NTH * V::KSH; ++i) whd[i] = L[V::whd + i * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < V::NT; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bh[4 * t + e] = L[V::bh + 16 * t + 4 * q + e];
-#pragma unroll
-    for (int t = 0; t < V::NTH; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bhd[4 * t + e] = L[V::bhd + 16 * t + 4 * q + e];
-#pragma unroll
-    for (int d = 0; d < MD; ++d) {
-      es[d] = L[V::es + d];
-      eq[d] = L[V::eq + d];
-    }
   }
 };
 
 // (S, T, Q) = net([a, b, t]) for the 16 chains of this wave; every lane returns its own chain's values.
-template <int HP, int MD, int KS_, int KSH_>
-__device__ __forceinline__ void net_eval_mfma(const NetRegs<HP, MD, KS_, KSH_>& W, int dim, int q_tanh,
-                                              const float (&a)[MD], const float (&b)[MD], float tc, float ts,
+template <int HP, int MD, int KS_, int KSH_, bool L1M>
+__device__ __forceinline__ void net_eval_mfma(const float* L, const NetRegs<HP, MD, KS_, KSH_, L1M>& W, int dim,
+                                              int q_tanh, const float (&a)[MD], const float (&b)[MD], float tc, float ts,
                                               int lane, float (&S)[MD], float (&T)[MD], float (&Q)[MD],
                                               [[maybe_unused]] unsigned long long* st = nullptr) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
-  constexpr int NT = V::NT, KSH = V::KSH, NTH = V::NTH, KS1 = V::KS1;
+  constexpr int NT = V::NT, KS = V::KS, KSH = V::KSH, NTH = V::NTH, KS1 = V::KS1, K1 = V::K1;
   const int q = lane >> 4, r = lane & 15;
   [[maybe_unused]] unsigned long long t0 = ST_NOW();
-  // ---- layer 1: this lane's entries 4 s + q of [a | b | cos t, sin t, 1, 0]
+  // ---- layer 1: h1[s] = relu(pre-activation of unit 4 s + q), the same ascending-k fma chain in both forms
+  constexpr int K2 = L1M ? KSH : KS;        // k-steps of the hidden layer: unit 16 t + 4 q + e at step 4 t + e (L1M), 4 s + q (VALU)
+  float h1[K2];
   f32x4s acc[NT];
+  if constexpr (L1M) {
 #pragma unroll
-  for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < KS1; ++s) {
-    float e4[4];
+    for (int s = 0; s < KS1; ++s) {
+      float e4[4];      // (built per step: the same values in one K1-entry array cost 6 us per cfg-2 propose)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = 4 * s + j;           // compile-time
-      e4[j] = k < MD ? a[k < MD ? k : 0] : k < 2 * MD ? b[(k >= MD && k < 2 * MD) ? k - MD : 0]
-              : k == 2 * MD ? tc : k == 2 * MD + 1 ? ts : k == 2 * MD + 2 ? 1.f : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * s + j;           // compile-time
+        e4[j] = k < MD ? a[k < MD ? k : 0] : k < 2 * MD ? b[(k >= MD && k < 2 * MD) ? k - MD : 0]
+                : k == 2 * MD ? tc : k == 2 * MD + 1 ? ts : k == 2 * MD + 2 ? 1.f : 0.f;
+      }
+      const float mine = q == 0 ? e4[0] : q == 1 ? e4[1] : q == 2 ? e4[2] : e4[3];
+#pragma unroll
+      for (int to = 0; to < NT; ++to)
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[to * KS1 + s], mine, acc[to], 0, 0, 0);
     }
-    const float in = q == 0 ? e4[0] : q == 1 ? e4[1] : q == 2 ? e4[2] : e4[3];
 #pragma unroll
-    for (int to = 0; to < NT; ++to)
-      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[to * KS1 + s], in, acc[to], 0, 0, 0);
+    for (int s = 0; s < K2; ++s) h1[s] = fmaxf(acc[s >> 2][s & 3], 0.f);
+  } else {
+    float in[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k)
+      in[k] = k < MD ? a[k < MD ? k : 0] : k < 2 * MD ? b[(k >= MD && k < 2 * MD) ? k - MD : 0]
+              : k == 2 * MD ? tc : k == 2 * MD + 1 ? ts : k == 2 * MD + 2 ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float* rec = L + V::rec + (4 * s + q) * K1;
+      float pre = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < K1; k4 += 4) {
+        const f32x4s w = *reinterpret_cast<const f32x4s*>(rec + k4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre = __builtin_fmaf(w[j], in[k4 + j], pre);
+      }
+      h1[s] = fmaxf(pre, 0.f);
+    }
   }
-  float h1[KSH];
-#pragma unroll
-  for (int s = 0; s < KSH; ++s) h1[s] = fmaxf(acc[s >> 2][s & 3], 0.f);
   ST_ADD(0, t0);
   t0 = ST_NOW();
   // ---- layer 2
 #pragma unroll
   for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < KSH; ++s)
+  for (int s = 0; s < K2; ++s)
 #pragma unroll
     for (int to = 0; to < NT; ++to)
-      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[to * KSH + s], h1[s], acc[to], 0, 0, 0);
+      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[to * K2 + s], h1[s], acc[to], 0, 0, 0);
   float h2[KSH];
 #pragma unroll
-  for (int s = 0; s < KSH; ++s) h2[s] = fmaxf(acc[s >> 2][s & 3] + W.bh[s], 0.f);
+  for (int s = 0; s < KSH; ++s) {
+    float bias;
+    if constexpr (L1M) bias = W.bh[s];
+    else bias = L[V::bh + 16 * (s >> 2) + 4 * q + (s & 3)];
+    h2[s] = fmaxf(acc[s >> 2][s & 3] + bias, 0.f);
+  }
   ST_ADD(1, t0);
   t0 = ST_NOW();
   // ---- heads
@@ -256,7 +307,9 @@ __device__ __forceinline__ void net_eval_mfma(const NetRegs<HP, MD, KS_, KSH_>& 
       if (s & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KSH + s], h2[s], c1, 0, 0, 0);
       else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KSH + s], h2[s], c0, 0, 0, 0);
     }
-    const f32x4s bias = {W.bhd[4 * th], W.bhd[4 * th + 1], W.bhd[4 * th + 2], W.bhd[4 * th + 3]};
+    f32x4s bias;
+    if constexpr (L1M) bias = f32x4s{W.bhd[4 * th], W.bhd[4 * th + 1], W.bhd[4 * th + 2], W.bhd[4 * th + 3]};
+    else bias = *reinterpret_cast<const f32x4s*>(L + V::bhd + 16 * th + 4 * q);
     hv[th] = c0 + c1 + bias;
   }
   ST_ADD(2, t0);
@@ -271,9 +324,9 @@ __device__ __forceinline__ void net_eval_mfma(const NetRegs<HP, MD, KS_, KSH_>& 
 #pragma unroll
   for (int d = 0; d < MD; ++d) {
     if (d < dim) {
-      S[d] = fast_tanh(out[d]) * W.es[d];
+      S[d] = fast_tanh(out[d]) * (L1M ? W.es[L1M ? d : 0] : L[V::es + d]);
       T[d] = out[MD + d];
-      Q[d] = (q_tanh ? fast_tanh(out[2 * MD + d]) : out[2 * MD + d]) * W.eq[d];
+      Q[d] = (q_tanh ? fast_tanh(out[2 * MD + d]) : out[2 * MD + d]) * (L1M ? W.eq[L1M ? d : 0] : L[V::eq + d]);
     }
   }
 #ifdef L2HMC_STAMPS
@@ -353,7 +406,7 @@ struct TargetRegs {
   }
 };
 
-template <int HP, int MD, int KS_, int KSH_>
+template <int HP, int MD, int KS_, int KSH_, bool L1M>
 __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTrajArgs a) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -367,8 +420,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   float* Lts = Lm + ((N * dim + 3) & ~3);         // (cos, sin) of 2 pi step / N, [N][2]
   float* scr_all = Lts + ((2 * N + 3) & ~3);                   // [waves][16 chains][NTH * 16]: hand-off patch of the propose epilogue
   if (!P.hmc) {
-    load_net_mfma<HP, MD, KS_, KSH_>(P.xnet, Lx, dim);
-    load_net_mfma<HP, MD, KS_, KSH_>(P.vnet, Lv, dim);
+    load_net_mfma<HP, MD, KS_, KSH_, L1M>(P.xnet, Lx, dim);
+    load_net_mfma<HP, MD, KS_, KSH_, L1M>(P.vnet, Lv, dim);
   }
   load_target(P.target, Lt);
   for (int i = threadIdx.x; i < N * dim; i += kSmallThreads) Lm[i] = P.masks[i];
@@ -380,7 +433,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   __syncthreads();                                // the only workgroup barrier of the kernel
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  NetRegs<HP, MD, KS_, KSH_> Wx, Wv;
+  NetRegs<HP, MD, KS_, KSH_, L1M> Wx, Wv;
   if (!P.hmc) {
     Wx.load(Lx, lane);
     Wv.load(Lv, lane);
@@ -446,7 +499,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
             const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
             bin[d] = k * x[d];
           }
-          if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, S, T, Q, st);
+          if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lx, Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, S, T, Q, st);
           [[maybe_unused]] const unsigned long long tu = ST_NOW();
 #pragma unroll
           for (int d = 0; d < MD; ++d) {
@@ -467,7 +520,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
         }
         target(x, &E1, g);
       }
-      if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_>(Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, S, T, Q, st);
+      if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lv, Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, S, T, Q, st);
       [[maybe_unused]] const unsigned long long tu2 = ST_NOW();
 #pragma unroll
       for (int d = 0; d < MD; ++d) {
@@ -548,14 +601,14 @@ static size_t small_mfma_lds(int dim, int K, int N) {
                           (size_t)(kSmallThreads / 64) * 16 * MfmaNet<HP, MD, KS_, KSH_>::NTH * 16);
 }
 
-template <int HP, int MD, int KS_, int KSH_>
-static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
+template <int HP, int MD, int KS_, int KSH_, bool L1M>
+static int launch_small_mfma_form(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
   const l2hmc_small_plan& P = a.plan;
   const size_t lds = small_mfma_lds<HP, MD, KS_, KSH_>(P.x_dim, P.target.K, P.trajectory_length);
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
   static DeviceOnce attr_once;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
   if (attr_once.pending()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<HP, MD, KS_, KSH_>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
@@ -563,13 +616,24 @@ static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) 
 #ifdef L2HMC_STAMPS
   SmallTrajArgs b = a;
   b.stamps = g_stamp_cls == 7 ? g_stamp_buf : nullptr;
-  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_>), grid, dim3(kSmallThreads), lds, st, b);
+  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>), grid, dim3(kSmallThreads), lds, st, b);
 #else
-  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_>), grid, dim3(kSmallThreads), lds, st, a);
+  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>), grid, dim3(kSmallThreads), lds, st, a);
 #endif
   prof_after(kProfSmall, st);
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;
+}
+
+// first layer on the matrix pipe while every wave has a SIMD to itself (<= 1024 waves of 16 chains), on the VALU for
+// larger batches; l2hmc_small_first_layer_form forces one form (they agree to rounding: tests)
+static std::atomic<int> g_small_l1_form{0};
+template <int HP, int MD, int KS_, int KSH_>
+static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
+  const int force = g_small_l1_form.load(std::memory_order_relaxed);
+  const bool l1m = force ? force == 1 : ceil_div(a.rows, 16) <= 1024;
+  return l1m ? launch_small_mfma_form<HP, MD, KS_, KSH_, true>(a, grid, st)
+             : launch_small_mfma_form<HP, MD, KS_, KSH_, false>(a, grid, st);
 }
 
 static int check_target(const l2hmc_mog_target* t) {
@@ -585,6 +649,12 @@ static int check_target(const l2hmc_mog_target* t) {
 }  // namespace l2hmc
 
 using namespace l2hmc;
+
+extern "C" int l2hmc_small_first_layer_form(int32_t form) {
+  L2HMC_REQUIRE(form >= 0 && form <= 2, "small_first_layer_form: 0 (by batch size), 1 (matrix pipe) or 2 (VALU)");
+  g_small_l1_form.store(form, std::memory_order_relaxed);
+  return L2HMC_OK;
+}
 
 extern "C" int l2hmc_mog_energy_grad(const l2hmc_mog_target* tgt, const float* x, int64_t rows, float* energy,
                                      float* grad, l2hmc_stream_t stream) {

@@ -47,6 +47,7 @@ pytestmark = pytest.mark.gpu
 TOL_OP = 1e-5
 TOL_P = 2e-5
 MAX_RATIO, Q999_RATIO, RMS_RATIO, P_RATIO = 5.0, 2.5, 1.6, 3.5     # measured allowances over the fp32 oracle's own error
+FORMS_TOL = 1e-4                                         # toy kernel's two first-layer forms (see the test)
 FUSED_VS_LAYERED_X, FUSED_VS_LAYERED_P = 5e-5, 1e-4       # full-size cfg 3, fused against layered (see the test)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 H_REG = H.REGIMES
@@ -555,6 +556,37 @@ def test_one_launch_propose_equals_the_piecewise_path_bit_for_bit(la, name, B):
     hm = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=3, eps=0.1, hmc=True)
     hplan = hm._plan()
     assert L.l2hmc_small_propose(C.byref(hplan), x.data_ptr(), B, seed, d0, None, Lv3.data_ptr(), None, None, None) != 0
+
+
+@pytest.mark.parametrize("name,B", [("mog_cfg2", 4096), ("mog_cfg2", 37), ("scg_cfg1", 128)])
+def test_both_first_layer_forms_of_the_toy_kernel_agree(la, name, B):
+    """Batches of at most one wave per SIMD evaluate the toy networks' first layer on the matrix pipe, chip-filling
+    ones on the VALU (csrc/small_mlp.hip); the forms walk the hidden layer's k in different orders, so `propose` and
+    both trajectory directions must agree to fp32 rounding (TOL_OP / TOL_P), and each form is deterministic."""
+    from l2hmc_amd import _lib
+    g, tgt, dyn = _small(la, name)
+    rng = np.random.default_rng(11)
+    x = torch.as_tensor(rng.standard_normal((B, 2)) * 0.7 + 0.3, dtype=torch.float32, device="cuda")
+    v = torch.as_tensor(rng.standard_normal((B, 2)), dtype=torch.float32, device="cuda")
+    outs = {}
+    try:
+        for form in (1, 2, 1):                  # 1 = matrix pipe, 2 = VALU
+            _lib.check(_lib.lib().l2hmc_small_first_layer_form(form))
+            dyn._draws = 20
+            Lx, _, px, mh = la.propose(x, dyn, do_mh_step=False)
+            Xf, Vf, pf = dyn.forward(x, init_v=v)
+            Xb, Vb, pb = dyn.backward(x, init_v=v)
+            now = (Lx, px, Xf, Vf, pf, Xb, Vb, pb)
+            if form in outs:
+                assert all(torch.equal(a, b) for a, b in zip(now, outs[form]))
+            outs[form] = now
+    finally:
+        _lib.check(_lib.lib().l2hmc_small_first_layer_form(0))
+    errs = [H.relerr(np_(a), np_(b)) for a, b in zip(outs[1], outs[2])]
+    print("toy kernel, matrix-pipe vs VALU first layer:", " ".join(f"{e:.1e}" for e in errs))
+    # two fp32 summation orders of the same N-step trajectory (measured: profiles/r03_gate_envelope.txt)
+    assert max(errs) < FORMS_TOL, errs
+    assert float(outs[1][1].mean()) > 0.01          # not a trivially rejected batch
 
 
 def test_generic_dynamics_hmc_and_quadratic_gaussian(la):

@@ -46,18 +46,21 @@ def main():
     calls = 4 * N
     print(f"cfg {cfg}: {B} chains, {N} LF, {len(s)} waves; wall of one propose {wall * 1e6:.1f} us (stamped build); "
           f"median wave {tot:.0f} cycles = {tot / calls:.0f} per network call")
-    names = ["first layer (VALU, K = 2 dim + 2)", "hidden layer (MFMA 16x16x4)", "heads (MFMA) + bias + patch store",
-             "patch round trip + tanh / exp(coeff)", "target energy + gradient", "sub-update arithmetic (exp, masks, log-det)"]
+    names = ["first layer (matrix pipe, K = 2 dim + 4)", "hidden layer (MFMA 16x16x4) + bias + relu", "heads (MFMA) + bias",
+             "ds_bpermute gather + tanh / exp(coeff)", "target energy + gradient", "sub-update arithmetic (exp, masks, log-det)"]
     acc = 0
     for i, n in enumerate(names):
         m = np.median(s[:, i])
         acc += m
         print(f"  {n:44s} {m:9.0f} cyc  {100 * m / tot:5.1f} %   {m / calls:7.0f} per call")
     print(f"  {'other (time encoding, loop, stamps)':44s} {tot - acc:9.0f} cyc  {100 * (tot - acc) / tot:5.1f} %")
-    ks, nt, ksh = {1: (3, 1, 4), 2: (13, 4, 14)}[cfg]
-    ideal = calls * (ks * nt + ksh) * 32
-    print(f"  MFMA issue cycles per wave ({ks} x {nt} + {ksh} instructions of 32 cycles per call): {ideal} = "
+    nt, ksh = {1: (1, 4), 2: (4, 14)}[cfg]          # latency form: first layer 2 x nt, hidden ksh x nt, heads ksh
+    n_mfma = 2 * nt + ksh * nt + ksh
+    ideal = calls * n_mfma * 32
+    print(f"  MFMA issue cycles per wave ({n_mfma} instructions of 32 cycles per call): {ideal} = "
           f"{100 * ideal / tot:.1f} % of the wave's cycles")
+    print("  (phase boundaries are taken at instruction ISSUE: a matrix instruction's completion is paid by the "
+          "first phase that reads its result; the per-call total is the reliable figure)")
 
 
 if __name__ == "__main__":

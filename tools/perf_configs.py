@@ -111,6 +111,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         from l2hmc_amd import _lib
         print("library:", _lib.LIB_PATH)
+        if len(sys.argv) > 2:               # 1: first layer on the matrix pipe, 2: on the VALU (default: by batch size)
+            _lib.check(_lib.lib().l2hmc_small_first_layer_form(int(sys.argv[2])))
+            print("first-layer form forced to", {1: "matrix pipe", 2: "VALU"}[int(sys.argv[2])])
         scg = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
         mog = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
         small("cfg1 SCG 2-D, B=128, 5 LF, H=10", scg, 128, 5, 10)
