@@ -421,6 +421,9 @@ static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, f
     if (int e = l2hmc_kinetic_energy(v, rows, D, w.kin0, stream)) return e;
   }
   const bool carry = carry_possible(p, x, v, w);
+  // (measured and dropped: the two halves of the batch on two streams, so that one half's launch boundaries and kernel
+  //  tails overlap the other half's matrix work -- half-size kernels lose more than the overlap returns: cfg 4
+  //  9.75 -> 10.18 ms, cfg 3 layered 2.58 -> 2.63 ms)
   for (int step = 0; step < p->num_steps; ++step)
     if (int e = leapfrog_step(p, beta, step, x, v, dir, rows, w, stream, carry, carry && step > 0,
                               carry && step + 1 < p->num_steps))
