@@ -48,7 +48,7 @@ TOL_OP = 1e-5
 TOL_P = 2e-5
 MAX_RATIO, Q999_RATIO, RMS_RATIO, P_RATIO = 5.0, 2.5, 1.6, 3.5     # measured allowances over the fp32 oracle's own error
 FORMS_TOL = 1e-4                                         # toy kernel's two first-layer forms (see the test)
-FUSED_VS_LAYERED_X, FUSED_VS_LAYERED_P = 5e-5, 1e-4       # full-size cfg 3, fused against layered (see the test)
+FUSED_VS_LAYERED_X, FUSED_VS_LAYERED_P = 1.5e-5, 2e-5    # full-size cfg 3, fused against layered: measured 4.4e-6 / 0
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 H_REG = H.REGIMES
 
