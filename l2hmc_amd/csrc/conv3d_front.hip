@@ -33,12 +33,15 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   const int T2 = T / 2, X2 = X / 2, T2P = T2 + 1, X2P = X2 + 1;   // conv2 pad (0 / 1)
   const int T4 = T / 4, X4 = X / 4;
   const int cpw = p.cpw;
+  // channel stride of the pooled conv1 map: F + 4 in the compile-time instances, whose second convolution runs on the
+  // matrix pipe (16-byte fragment reads of 16 positions: rows of 20 / 12 floats fall on distinct bank groups)
+  const int FS = FT ? F + 4 : F;
   float* w1 = lds;                                 // [3][3][2][F]
   float* b1 = w1 + 18 * F;
-  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice)
-  float* b2 = w2 + 4 * F * F2;
+  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice); FT > 0: [2F][4 F + 4] (g, tap * F + c)
+  float* b2 = w2 + (FT ? F2 * (4 * F + 4) : 4 * F * F2);
   float* xin = b2 + F2;                            // [cpw][TP][XP][2]
-  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][F]
+  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][FS]
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * cpw;
   const int nrow = (int)min((int64_t)cpw, p.rows - row0);
@@ -50,11 +53,13 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   for (int i = tid; i < 4 * F * F2; i += kConvThreads) {
     // Keras kernel [di][dj][dd][c][g]: keep dd = 0
     const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
-    w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
+    const float wv = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
+    if (FT) w2[g * (4 * F + 4) + tap * F + c] = wv;      // k-contiguous per output filter: the MFMA's weight fragments
+    else w2[i] = wv;
   }
   for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
   for (int i = tid; i < cpw * TP * XP * 2; i += kConvThreads) xin[i] = 0.f;
-  for (int i = tid; i < cpw * T2P * X2P * F; i += kConvThreads) p1[i] = 0.f;
+  for (int i = tid; i < cpw * T2P * X2P * FS; i += kConvThreads) p1[i] = 0.f;
   __syncthreads();
   const float* in = p.in[which];
   const bool masked = which == 1 && p.cmask_f != nullptr;
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
     // Compile-time shapes (the BASELINE configurations): a thread owns a PAIR of filters, so every multiply-add is a
     // v_pk_fma_f32; the pair's 18 conv1 taps stay in registers (the workgroup size is a multiple of F / 2) and the
     // 4 x 4 x 2 input patch under a pooling window is read once (16 ds_read_b64 instead of 144 scalar reads).
-    constexpr int FP = FT / 2, GP = FT;
+    constexpr int FP = FT / 2;
     static_assert(kConvThreads % FP == 0 && FT % 2 == 0, "filter pairs must stay with their threads");
     {
       const int fp = tid % FP;
@@ -120,48 +125,69 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
             m[1] = fmaxf(m[1], fmaxf(v0[1], v1[1]));
           }
         }
-        *reinterpret_cast<f32x2*>(p1 + ((c * T2P + I) * X2P + J) * F + 2 * fp) = f32x2{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f)};
+        *reinterpret_cast<f32x2*>(p1 + ((c * T2P + I) * X2P + J) * FS + 2 * fp) = f32x2{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f)};
       }
     }
     __syncthreads();
-    const int n2 = nrow * T4 * X4 * GP;
-    for (int idx = tid; idx < n2; idx += kConvThreads) {
-      const int gp = idx % GP;
-      int r = idx / GP;
-      const int J2 = r % X4;
-      r /= X4;
-      const int I2 = r % T4, c = r / T4;
-      const f32x2 bias = *reinterpret_cast<const f32x2*>(b2 + 2 * gp);
-      f32x2 acc[2][2] = {{bias, bias}, {bias, bias}};
-      const float* pbase = p1 + ((c * T2P + 2 * I2) * X2P + 2 * J2) * F;
-      for (int ch4 = 0; ch4 < F; ch4 += 4) {
-        f32x4 w[3][3];
+    // conv2 (2,2,[2]) + relu + pool on the matrix pipe: per chain a [T2 X2 positions] x [4 F] x [2 F] product.
+    // v_mfma_f32_16x16x4_f32 with the WEIGHTS as first operand (16 filters x 4 k) and 16 positions as second: lane
+    // (q, r) supplies tap q = (di, dj) of position r, channels 4 s .. 4 s + 3 (one ds_read_b128 per step s, element e =
+    // channel 4 s + e), and receives out[position r][filters 16 gt + 4 q .. + 3].  A wave takes one 16-position tile
+    // with every filter tile; the 2 x 2 pooling partners of a position are lanes r ^ 1 and r ^ X2.
+    // (The VALU form this replaces spent 25 LDS reads per 64 packed multiply-adds: LDS-throughput-bound.)
+    {
+      constexpr int PT = (LT / 2) * (LT / 2) / 16;        // 16-position tiles per chain (16 x 16: 4; 8 x 8: 1)
+      constexpr int GT = 2 * FT / 16;                     // 16-filter tiles (F = 16: 2; F = 8: 1)
+      constexpr int NS = FT / 4;                          // k-steps per tap group (4 channels each)
+      constexpr int RW = 16 / (LT / 2) < 1 ? 1 : 16 / (LT / 2);   // rows of the position grid per tile (2 or 4)
+      constexpr int WK = 4 * FT + 4;
+      static_assert(LT / 2 <= 8 && (LT / 2) * (LT / 2) % 16 == 0 && (2 * FT) % 16 == 0 && FT % 4 == 0,
+                    "a 16-position tile must hold whole 2 x 2 pooling windows");
+      const int lane = tid & 63, wave = tid >> 6;
+      const int q = lane >> 4, r = lane & 15;
+      const int di = q >> 1, dj = q & 1;
+      // this lane's weight fragments: filter 16 gt + r, tap q, channels 4 s .. 4 s + 3
+      f32x4 wf[GT][NS];
 #pragma unroll
-        for (int wi = 0; wi < 3; ++wi)
+      for (int gt = 0; gt < GT; ++gt)
 #pragma unroll
-          for (int wj = 0; wj < 3; ++wj)
-            w[wi][wj] = *reinterpret_cast<const f32x4*>(pbase + (wi * X2P + wj) * F + ch4);
+        for (int sx = 0; sx < NS; ++sx)
+          wf[gt][sx] = *reinterpret_cast<const f32x4*>(w2 + (16 * gt + r) * WK + q * FT + 4 * sx);
+      f32x4 bias[GT];
 #pragma unroll
-        for (int di = 0; di < 2; ++di)
+      for (int gt = 0; gt < GT; ++gt) bias[gt] = *reinterpret_cast<const f32x4*>(b2 + 16 * gt + 4 * q);
+      for (int item = wave; item < nrow * PT; item += kConvThreads / 64) {
+        const int c = item / PT, pt = item - c * PT;
+        const int I = pt * RW + r / X2, J = r % X2;       // this lane's position
+        const float* pb = p1 + ((c * T2P + I + di) * X2P + J + dj) * FS;
+        f32x4 acc[GT];
 #pragma unroll
-          for (int dj = 0; dj < 2; ++dj)
+        for (int gt = 0; gt < GT; ++gt) acc[gt] = bias[gt];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              const f32x2 kw = *reinterpret_cast<const f32x2*>(w2 + ((di * 2 + dj) * F + ch4 + cc) * F2 + 2 * gp);
+        for (int sx = 0; sx < NS; ++sx) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(pb + 4 * sx);
 #pragma unroll
-              for (int a = 0; a < 2; ++a)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                  const float xv = w[a + di][bb + dj][cc];
-                  acc[a][bb] += f32x2{xv, xv} * kw;
-                }
-            }
+            for (int gt = 0; gt < GT; ++gt)
+              acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gt][sx][e], a[e], acc[gt], 0, 0, 0);
+        }
+        // relu + 2 x 2 max-pool across the position lanes (max and relu commute)
+#pragma unroll
+        for (int gt = 0; gt < GT; ++gt) {
+          f32x4 m = acc[gt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
+            m[e] = fmaxf(m[e], __shfl_xor(m[e], X2 >= 16 ? 0 : X2, 64));
+            m[e] = fmaxf(m[e], 0.f);
+          }
+          if ((J & 1) == 0 && (I & 1) == 0) {
+            float* o = out + (row0 + c) * p.ldo + ((I >> 1) * X4 + (J >> 1)) * F2 + 16 * gt + 4 * q;
+            *reinterpret_cast<f32x4*>(o) = m;
+          }
+        }
       }
-      const float m0 = fmaxf(fmaxf(acc[0][0][0], acc[0][1][0]), fmaxf(acc[1][0][0], acc[1][1][0]));
-      const float m1 = fmaxf(fmaxf(acc[0][0][1], acc[0][1][1]), fmaxf(acc[1][0][1], acc[1][1][1]));
-      float* o = out + (row0 + c) * p.ldo + (I2 * X4 + J2) * F2 + 2 * gp;
-      o[0] = fmaxf(m0, 0.f);
-      o[1] = fmaxf(m1, 0.f);
     }
     return;
   }
@@ -244,10 +270,14 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                 "conv3d front-end: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
   const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
   a.cpw = per_chain >= 1024 ? 1 : (1024 / per_chain > 8 ? 8 : 1024 / per_chain);   // amortise filter loads / barriers
+  if (per_chain >= 1024 && per_chain < 4096) a.cpw = 2;      // 16 x 16, F = 16: 32.7 -> 31.0 us per launch (two chains share the filter load)
   if (a.ldi == 0) a.ldi = 2 * a.T * a.X;
-  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F +
+  // compile-time instances: k-contiguous conv2 weights with a 4-float row pad, pooled map with channel stride F + 4
+  const bool inst = (a.F == 8 && a.T == 8 && a.X == 8) || (a.F == 16 && a.T == 16 && a.X == 16);
+  const size_t fs = inst ? a.F + 4 : a.F;
+  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + (inst ? 8 * a.F : 0) + 2 * a.F +
                                       (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
-                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * a.F);
+                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * fs);
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
   L2HMC_REQUIRE(a.only >= 0 && a.only <= 2, "conv3d front-end: bad input selector %d", a.only);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), a.only ? 1 : 2);
