@@ -10,7 +10,7 @@ OUT="$ROOT/gpurun_out/$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5"
-LIGHT="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-roofline"
+LIGHT="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-roofline --no-configs-table"
 echo "== kernel trace + stats of the default bench command"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $BENCH > "$OUT/stats.log" 2>&1
 echo "== SQ pass 1 (MFMA instruction counters, wave cycles)"
