@@ -115,9 +115,11 @@ typedef struct l2hmc_dense_net {
 
 /* Fragment-ordered copy of (w1_t, wh_t, whd_t) for the whole-trajectory kernel:
  * [wave][k-chunk][n-tile][lane][4] per layer, so every B-operand load of a wave is
- * one contiguous 1 KiB read.  pack_bytes() is 0 when the shape has no fused kernel
- * (then leave .packed NULL: the layer-by-layer kernels are used).  Re-pack after
- * every weight update. */
+ * one contiguous 1 KiB read.  GenericNet plans get a second image behind it for the
+ * kernel's sub-tile form ([wave][k-chunk][64-column block][4][lane][4]; batches that cannot
+ * put a 16-row tile on every CU run 4 / 8 / 12 rows per workgroup, bit-identical results).
+ * pack_bytes() is 0 when the shape has no fused kernel (then leave .packed NULL: the
+ * layer-by-layer kernels are used).  Re-pack after every weight update. */
 size_t l2hmc_dense_pack_bytes(const l2hmc_dense_net* net);
 int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc_stream_t stream);
 

@@ -24,6 +24,9 @@
 // shared by the 4 waves and read from LDS with conflict-free ds_read_b128
 // (row stride = K + 8 floats).
 #include "fused_common.h"
+#include "fused_args.h"
+#include <atomic>
+#include <stdlib.h>
 
 namespace l2hmc {
 
@@ -115,38 +118,7 @@ __global__ void pack_fused_kernel(l2hmc_dense_net n, float* __restrict__ out, in
 #define FT_ADD(slot, t0) do {} while (0)
 #endif
 
-struct FusedArgs {
-  int T, X, num_steps, step_begin, step_end;
-  float eps, beta;
-  const float* masks;                    // [num_steps][D]
-  l2hmc_dense_net xnet, vnet;            // .packed must be set
-  l2hmc_conv3d_front xfront, vfront;     // ConvNet3D only
-  const float* x0; const float* v0;      // [rows][D]
-  const int* dir;                        // [rows] or NULL
-  int64_t x_mod;                         // > 0: row r starts from x0[r % x_mod] (both directions of one batch)
-  int64_t dir_split;                     // dir == NULL and > 0: rows >= dir_split integrate backward
-  int64_t rows;
-  float* x_out; float* v_out;            // [rows][D]
-  float* logdet;                         // [rows] or NULL; written (=) or accumulated (+=)
-  int logdet_accumulate;
-  float* p_accept;                       // [rows] or NULL
-  unsigned long long* stamps;            // diagnostic builds only
-  int stagger;                           // cycles of start delay per in-XCD workgroup index (0 = none)
-  FusedTape tx, tv;                      // training tape per network (all-NULL = sampling)
-  // Whole-MCMC-step mode (l2hmc_gauge_mcmc_step, l2hmc_gauge_transition_draw; step_B > 0): the kernel draws its own momenta / coin /
-  // MH uniform (Philox streams (seed, 2 draw) and (seed, 2 draw + 1), bit-identical to l2hmc_fill_*), integrates,
-  // mixes, accepts, measures and wraps -- ONE launch per MCMC step.  A workgroup then owns 8 chains x both
-  // directions (rows 0-7 forward, 8-15 backward of the same chains) or, with step_both = 0, 16 chains in the
-  // direction their coin selects; x0 = the step's input samples [B][D], v0 / dir / x_out / v_out are unused.
-  float* step_x_next;                    // [B][D] wrapped output samples (may alias x0), or NULL
-  float* step_xprop; float* step_vprop; float* step_xout;   // [B][D] apply_transition's outputs (unwrapped), or NULL
-  int64_t step_B;                        // > 0 switches the mode on
-  unsigned long long step_seed, step_draw;
-  int step_both;
-  float* step_px; float* step_act; float* step_plq; float* step_chg; float* step_dq;   // [B] each, or NULL
-  float* step_sums;                      // [4] = [sum p, sum |dQ|, B, ticket] or NULL; ticket 0 on entry, left 0
-  float* step_part;                      // [2 * workgroups] scratch for the fixed-order sums
-};
+// (struct FusedArgs: fused_args.h, shared with the sub-tile form in fused_traj4.hip)
 
 #ifdef L2HMC_STAMPS
 int g_fused_stagger = 0;
@@ -956,6 +928,22 @@ static int fused_conv_net(const l2hmc_dense_net* n) {
 }
 int fused_net_supported(const l2hmc_dense_net* n) { return fused_generic_net(n) || fused_conv_net(n); }
 
+// L2HMC_FUSED_SUBTILE=0 keeps every batch on the 16-row form (A/B and the bit-identity test)
+static std::atomic<int> g_subtile{-1};
+static bool subtile_enabled() {
+  int v = g_subtile.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("L2HMC_FUSED_SUBTILE");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_subtile.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+extern "C" int l2hmc_debug_fused_subtile(int on) {
+  g_subtile.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+
 int fused_plan_supported(const l2hmc_gauge_plan* p) {
   if (p->hmc || !p->xnet.packed || !p->vnet.packed || 2 * p->T * p->X != 128 || (p->X & (p->X - 1)) != 0) return 0;
   if (p->flags & L2HMC_PLAN_CONV3D)
@@ -1020,6 +1008,9 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
   a.stagger = g_fused_stagger;
 #endif
+  // batches that cannot put a 16-row tile on every CU: the sub-tile form (4 or 8 rows per workgroup, same bits)
+  if (!conv && !tape && subtile_enabled())
+    if (const int rpw = fused4_rows_per_wg(rows)) return launch_fused4(a, rpw, stream);
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
   if (conv && tape)
@@ -1058,13 +1049,15 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
     step_once.done();
   }
   L2HMC_REQUIRE(x_in && (x_next || x_out) && B > 0 && (!step_sums || part), "fused step: bad arguments");
-  const int cpw = both ? kFM / 2 : kFM;
+  const int rpw4 = (!conv && subtile_enabled()) ? fused4_rows_per_wg(B * (both ? 2 : 1)) : 0;
+  const int rpw = rpw4 ? rpw4 : kFM;                         // rows per workgroup: sub-tile form for small batches
+  const int cpw = both ? rpw / 2 : rpw;
   const int64_t nwg = ceil_div(B, cpw);
   FusedArgs a{};
   a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = 0; a.step_end = p->num_steps;
   a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
   a.xfront = p->xfront; a.vfront = p->vfront;
-  a.x0 = x_in; a.rows = nwg * kFM;
+  a.x0 = x_in; a.rows = nwg * rpw;
   a.step_x_next = x_next; a.step_xprop = x_prop; a.step_vprop = v_prop; a.step_xout = x_out; a.step_B = B; a.step_seed = seed; a.step_draw = draw; a.step_both = both;
   a.step_px = px; a.step_act = actions; a.step_plq = plaqs; a.step_chg = charges; a.step_dq = dq;
   a.step_sums = step_sums; a.step_part = part;
@@ -1072,6 +1065,7 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
   a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
   a.stagger = g_fused_stagger;
 #endif
+  if (rpw4) return launch_fused4(a, rpw4, stream);
   prof_before(kProfFused, stream);
   if (conv)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3((unsigned)nwg), dim3(CfgC::THREADS), lds, stream, a);
@@ -1088,7 +1082,9 @@ using namespace l2hmc;
 
 extern "C" size_t l2hmc_dense_pack_bytes(const l2hmc_dense_net* net) {
   if (!net || !fused_net_supported(net)) return 0;
-  return sizeof(float) * ((size_t)(net->Ka + net->Kb) * net->H + (size_t)net->H * net->H + (size_t)3 * net->D * net->H);
+  // the 16-row form's image, then (GenericNet plans) the sub-tile form's (fused_traj4.hip)
+  return sizeof(float) * ((size_t)(net->Ka + net->Kb) * net->H + (size_t)net->H * net->H + (size_t)3 * net->D * net->H +
+                          fused4_pack_floats(net));
 }
 
 extern "C" int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc_stream_t stream) {
@@ -1099,5 +1095,8 @@ extern "C" int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc
   const int waves = fused_conv_net(net) ? FusedCfg<128, 256, 64, true>::WAVES : FusedCfg<128, 512, 128, false>::WAVES;
   hipLaunchKernelGGL(pack_fused_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *net, packed, waves);
   L2HMC_CHECK_LAUNCH("dense_pack");
+  if (fused4_pack_floats(net))
+    return launch_fused4_pack(net, packed + (size_t)(net->Ka + net->Kb) * net->H + (size_t)net->H * net->H +
+                                        (size_t)3 * net->D * net->H, (hipStream_t)stream);
   return L2HMC_OK;
 }

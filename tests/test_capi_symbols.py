@@ -112,7 +112,8 @@ def test_training_entry_points_check_arguments_on_the_host(L):
 
 def test_workspace_queries(L):
     net = _lib.DenseNet(D=128, H=512, Ka=128, Kb=128)
-    assert L.l2hmc_dense_pack_bytes(C.byref(net)) == 4 * (256 * 512 + 512 * 512 + 384 * 512)
+    # the 16-row image (every weight once) + the sub-tile form's image (heads padded to two 64-lane blocks per wave)
+    assert L.l2hmc_dense_pack_bytes(C.byref(net)) == 4 * ((256 * 512 + 512 * 512 + 384 * 512) + (256 * 512 + 512 * 512 + 512 * 512))
     plan = _lib.GaugePlan(T=8, X=8, num_steps=10, hmc=0, xnet=net, vnet=net)
     one = L.l2hmc_gauge_ws_bytes(C.byref(plan), 4096)
     assert one >= 2 * 4096 * 512 * 4 + 4096 * 128 * 4

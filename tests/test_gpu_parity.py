@@ -1339,3 +1339,50 @@ def test_kept_products_equal_recomputed(la, L, arch, N, B):
     # and the kept-product path is a correct trajectory (forward, against the oracle)
     want = orc.transition_kernel(x, 2.0, v0f, forward=True)
     assert H.relerr(np_(outs[False][0]), want[0]) < 2 * TOL_OP and H.relerr(np_(outs[False][1]), want[1]) < 2 * TOL_OP
+
+
+# ----------------------------------------------------------------- sub-tile form of the whole-trajectory kernel
+@pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536])
+def test_subtile_form_equals_16_row_form(la, B):
+    """Batches that cannot put a 16-row tile on every CU run the whole-trajectory kernel in its sub-tile form (4, 8 or 12
+    rows per workgroup on v_mfma_f32_4x4x1_16B_f32, csrc/fused_traj4.hip).  Same k order, same epilogue expressions,
+    same grouping of every sum, same Philox indexing: a whole MCMC step, the trajectories alone (both directions, per-row
+    directions) and single leapfrog steps must EQUAL the 16-row form bit for bit; and the sub-tile form agrees with
+    the oracle on its own."""
+    from l2hmc_amd import _lib, GaugeSampler
+    T = X = 8
+    N, eps, beta = 4, 0.2, 2.0
+    orc, _, dyn = _pair(T, X, N, eps, B, "mild", True)
+    rng = np.random.default_rng(21)
+    x = torch.as_tensor(rng.uniform(0, 2 * np.pi, (B, 128)), dtype=torch.float32, device="cuda")
+    v = torch.as_tensor(rng.standard_normal((B, 128)), dtype=torch.float32, device="cuda")
+    L = _lib.lib()
+    outs = {}
+    try:
+        for sub in (1, 0):
+            L.l2hmc_debug_fused_subtile(sub)
+            dyn._draws = 40
+            smp = GaugeSampler(dyn)
+            xn, px, obs, dq = smp.step(x, beta)
+            dyn._draws = 40
+            tr = dyn.apply_transition(x, beta)                                   # library draws: the step kernel
+            f = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
+            b = dyn.transition_kernel(x, beta, forward=False, momentum=v, return_logdet=True)
+            lf = dyn._forward_lf(x, v, beta, 2) + dyn._backward_lf(x, v, beta, 1)
+            dyn.both_directions = False
+            dyn._draws = 40
+            sel = GaugeSampler(dyn).step(x, beta)[:2]
+            dyn.both_directions = True
+            outs[sub] = [xn, px, obs["action"], obs["avg_plaq"], obs["top_charge"], dq, *tr, *f, *b, *lf, *sel,
+                         smp.stats.mean_accept()]
+    finally:
+        L.l2hmc_debug_fused_subtile(1)
+    for i, (a, b_) in enumerate(zip(outs[1][:-1], outs[0][:-1])):
+        assert torch.equal(a, b_), f"output {i} differs between the sub-tile and the 16-row form"
+    # the step's mean accept probability is a fixed-order sum of per-WORKGROUP partial sums: another grouping of the
+    # same per-chain values (which are equal), so it agrees to fp32 rounding
+    assert abs(outs[1][-1] - outs[0][-1]) <= 1e-6 * max(abs(outs[0][-1]), 1e-30) + 1e-12
+    want = orc.transition_kernel(np_(x), beta, np_(v), forward=True)
+    got = outs[1][10:14]
+    assert H.relerr(np_(got[0]), want[0]) < 2 * TOL_OP and H.relerr(np_(got[1]), want[1]) < 2 * TOL_OP
+    assert np.abs(np_(got[2]) - want[2]).max() < TOL_P
