@@ -30,7 +30,10 @@ struct FusedArgs {
   // direction their coin selects; x0 = the step's input samples [B][D], v0 / dir / x_out / v_out are unused.
   float* step_x_next;                    // [B][D] wrapped output samples (may alias x0), or NULL
   float* step_xprop; float* step_vprop; float* step_xout;   // [B][D] apply_transition's outputs (unwrapped), or NULL
-  int64_t step_B;                        // > 0 switches the mode on
+  int64_t step_B;                        // > 0 switches the mode on: chains of the WHOLE batch (Philox stream offsets, count)
+  int64_t step_Bl, step_chain0;          // chains of THIS launch and the first one's index in the batch; the per-chain
+                                         // pointers (x0, step_x_next, step_px, ...) are already moved to that chain
+  int step_sums_acc;                     // 1: add this launch's sums to step_sums (second launch of a batch cut in two)
   unsigned long long step_seed, step_draw;
   int step_both;
   float* step_px; float* step_act; float* step_plq; float* step_chg; float* step_dq;   // [B] each, or NULL

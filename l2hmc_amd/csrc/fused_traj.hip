@@ -189,9 +189,9 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   if (STEPM) {
     if (tid < cpw) {
       const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
-      const bool lv = chain < p.step_B;
-      scoin[tid] = lv ? philox_u01((uint64_t)chain, 2 * p.step_draw + 1) : 1.f;
-      su[tid] = lv ? philox_u01((uint64_t)(p.step_B + chain), 2 * p.step_draw + 1) : 1.f;
+      const bool lv = chain < p.step_Bl;          // (streams are indexed by the chain's place in the WHOLE batch)
+      scoin[tid] = lv ? philox_u01((uint64_t)(p.step_chain0 + chain), 2 * p.step_draw + 1) : 1.f;
+      su[tid] = lv ? philox_u01((uint64_t)(p.step_B + p.step_chain0 + chain), 2 * p.step_draw + 1) : 1.f;
     }
     __syncthreads();
     for (int i = tid; i < kFM * (D / 4); i += kFThreads) {
@@ -200,10 +200,10 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
       const int dsel = p.step_both ? (rr >= kFM / 2 ? 1 : 0) : (scoin[k] > 0.5f ? 0 : 1);   // gauge_dynamics.py:221-227
       f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         xv = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
         // momentum of (direction dsel, chain): elements [(dsel * B + chain) * D, + D) of the normal stream
-        const uint64_t nb = (((uint64_t)dsel * (uint64_t)p.step_B + (uint64_t)chain) * D + c4) >> 2;
+        const uint64_t nb = (((uint64_t)dsel * (uint64_t)p.step_B + (uint64_t)(p.step_chain0 + chain)) * D + c4) >> 2;
         uint32_t c[4] = {(uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)(2 * p.step_draw), (uint32_t)((2 * p.step_draw) >> 32)};
         philox4x32_10(c, (uint32_t)p.step_seed, (uint32_t)(p.step_seed >> 32));
         float nv[4];
@@ -745,7 +745,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
       f32x4 xin = {0.f, 0.f, 0.f, 0.f};
-      if (chain < p.step_B) xin = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
+      if (chain < p.step_Bl) xin = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
       f32x4 xp;
       float pk;
       if (p.step_both) {
@@ -763,7 +763,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       *reinterpret_cast<f32x4*>(gin + k * SX + c4) = xin;
       *reinterpret_cast<f32x4*>(gout + k * SX + c4) = xo;
       if (c4 == 0) sobs[k * 4 + 3] = pk;
-      if (chain < p.step_B) {                                        // apply_transition's own outputs (:259)
+      if (chain < p.step_Bl) {                                       // apply_transition's own outputs (:259)
         if (p.step_xprop) *reinterpret_cast<f32x4*>(p.step_xprop + chain * D + c4) = xp;
         if (p.step_xout) *reinterpret_cast<f32x4*>(p.step_xout + chain * D + c4) = xo;
         if (p.step_vprop) {
@@ -810,7 +810,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     const float inv2pi = 0.15915494309189533577f;
     if (tid < cpw) {
       const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         const float q_in = sobs[tid * 4 + 1] * inv2pi, q_out = sobs[tid * 4 + 2] * inv2pi;
         if (p.step_px) p.step_px[chain] = sobs[tid * 4 + 3];
         if (p.step_act) p.step_act[chain] = (float)sites - sobs[tid * 4 + 0];      // sum (1 - cos P)
@@ -826,7 +826,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       if (tid == 0) {
         float a0 = 0.f, a1 = 0.f;
         for (int k = 0; k < cpw; ++k) {
-          if ((int64_t)blockIdx.x * cpw + k < p.step_B) {
+          if ((int64_t)blockIdx.x * cpw + k < p.step_Bl) {
             a0 += sobs[k * 4 + 3];
             a1 += fabsf(sobs[k * 4 + 1] * inv2pi - sobs[k * 4 + 2] * inv2pi);
           }
@@ -856,8 +856,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           __syncthreads();
         }
         if (tid == 0) {
-          p.step_sums[0] = fin[0];
-          p.step_sums[1] = fin[kFThreads];
+          p.step_sums[0] = p.step_sums_acc ? p.step_sums[0] + fin[0] : fin[0];          // (a batch cut into two launches)
+          p.step_sums[1] = p.step_sums_acc ? p.step_sums[1] + fin[kFThreads] : fin[kFThreads];
           p.step_sums[2] = (float)p.step_B;
           *reinterpret_cast<int*>(p.step_sums + 3) = 0;
         }
@@ -867,7 +867,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     for (int i = tid; p.step_x_next && i < cpw * (D / 4); i += kFThreads) {
       const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         f32x4 w = *reinterpret_cast<const f32x4*>(gout + k * SX + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -938,6 +938,18 @@ static bool subtile_enabled() {
     g_subtile.store(v, std::memory_order_relaxed);
   }
   return v != 0;
+}
+// CUs of the current device (one 16-row workgroup each per round); asked once per device
+static int device_cu_count() {
+  static std::atomic<int> cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 extern "C" int l2hmc_debug_fused_subtile(int on) {
   g_subtile.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -1049,30 +1061,64 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
     step_once.done();
   }
   L2HMC_REQUIRE(x_in && (x_next || x_out) && B > 0 && (!step_sums || part), "fused step: bad arguments");
-  const int rpw4 = (!conv && subtile_enabled()) ? fused4_rows_per_wg(B * (both ? 2 : 1)) : 0;
-  const int rpw = rpw4 ? rpw4 : kFM;                         // rows per workgroup: sub-tile form for small batches
-  const int cpw = both ? rpw / 2 : rpw;
-  const int64_t nwg = ceil_div(B, cpw);
-  FusedArgs a{};
-  a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = 0; a.step_end = p->num_steps;
-  a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
-  a.xfront = p->xfront; a.vfront = p->vfront;
-  a.x0 = x_in; a.rows = nwg * rpw;
-  a.step_x_next = x_next; a.step_xprop = x_prop; a.step_vprop = v_prop; a.step_xout = x_out; a.step_B = B; a.step_seed = seed; a.step_draw = draw; a.step_both = both;
-  a.step_px = px; a.step_act = actions; a.step_plq = plaqs; a.step_chg = charges; a.step_dq = dq;
-  a.step_sums = step_sums; a.step_part = part;
+  // Which form runs which chains.  The 16-row form covers 16 * (number of CUs) rows per round of workgroups, so a
+  // batch one chain past a round costs a whole further round; the sub-tile form (fused_traj4.hip: 4 / 8 / 12 rows
+  // per workgroup, same arithmetic per row, same bits) takes a batch that is small as a whole, or the remainder of
+  // a large one in a second launch on the same stream (chains [b_main, B): global chain indices for the Philox
+  // streams, pointers moved to the first chain of the part, the step's sums added to the first launch's).
+  const int ndir = both ? 2 : 1;
+  int64_t b_main = B;
+  int rpw_tail = 0;
+  if (!conv && subtile_enabled()) {
+    const int all = fused4_rows_per_wg(B * ndir);
+    if (all) {
+      b_main = 0; rpw_tail = all;
+    } else {
+      const int64_t round = (int64_t)kFM * device_cu_count() / ndir;     // chains in one full round of 16-row workgroups
+      const int64_t full = B / round * round;
+      const int r = (full > 0 && B > full) ? fused4_rows_per_wg((B - full) * ndir) : 0;
+      if (r) { b_main = full; rpw_tail = r; }
+    }
+  }
+  auto part_of = [&](int64_t c0, int64_t nb, int rpw, int accumulate) {
+    const int cpw = both ? rpw / 2 : rpw;
+    const int64_t D = 2 * (int64_t)p->T * p->X;
+    FusedArgs a{};
+    a.T = p->T; a.X = p->X; a.num_steps = p->num_steps; a.step_begin = 0; a.step_end = p->num_steps;
+    a.eps = p->eps; a.beta = beta; a.masks = p->masks; a.xnet = p->xnet; a.vnet = p->vnet;
+    a.xfront = p->xfront; a.vfront = p->vfront;
+    a.x0 = x_in + c0 * D; a.rows = ceil_div(nb, cpw) * rpw;
+    a.step_x_next = x_next ? x_next + c0 * D : nullptr;
+    a.step_xprop = x_prop ? x_prop + c0 * D : nullptr;
+    a.step_vprop = v_prop ? v_prop + c0 * D : nullptr;
+    a.step_xout = x_out ? x_out + c0 * D : nullptr;
+    a.step_B = B; a.step_Bl = nb; a.step_chain0 = c0; a.step_sums_acc = accumulate;
+    a.step_seed = seed; a.step_draw = draw; a.step_both = both;
+    a.step_px = px ? px + c0 : nullptr; a.step_act = actions ? actions + c0 : nullptr;
+    a.step_plq = plaqs ? plaqs + c0 : nullptr; a.step_chg = charges ? charges + c0 : nullptr;
+    a.step_dq = dq ? dq + c0 : nullptr;
+    a.step_sums = step_sums; a.step_part = part;
 #ifdef L2HMC_STAMPS
-  a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
-  a.stagger = g_fused_stagger;
+    a.stamps = g_stamp_cls == 5 ? g_stamp_buf : nullptr;
+    a.stagger = g_fused_stagger;
 #endif
-  if (rpw4) return launch_fused4(a, rpw4, stream);
-  prof_before(kProfFused, stream);
-  if (conv)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3((unsigned)nwg), dim3(CfgC::THREADS), lds, stream, a);
-  else
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3((unsigned)nwg), dim3(CfgG::THREADS), lds, stream, a);
-  prof_after(kProfFused, stream);
-  L2HMC_CHECK_LAUNCH("gauge_traj_fused (step)");
+    return a;
+  };
+  if (b_main > 0) {
+    FusedArgs a = part_of(0, b_main, kFM, 0);
+    const unsigned nwg = (unsigned)(a.rows / kFM);
+    prof_before(kProfFused, stream);
+    if (conv)
+      hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), dim3(nwg), dim3(CfgC::THREADS), lds, stream, a);
+    else
+      hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3(nwg), dim3(CfgG::THREADS), lds, stream, a);
+    prof_after(kProfFused, stream);
+    L2HMC_CHECK_LAUNCH("gauge_traj_fused (step)");
+  }
+  if (rpw_tail) {
+    FusedArgs a = part_of(b_main, B - b_main, rpw_tail, b_main > 0);
+    return launch_fused4(a, rpw_tail, stream);
+  }
   return L2HMC_OK;
 }
 

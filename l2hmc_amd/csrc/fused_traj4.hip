@@ -176,9 +176,9 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
   if (STEPM) {
     if (tid < cpw) {
       const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
-      const bool lv = chain < p.step_B;
-      scoin[tid] = lv ? philox_u01((uint64_t)chain, 2 * p.step_draw + 1) : 1.f;
-      su[tid] = lv ? philox_u01((uint64_t)(p.step_B + chain), 2 * p.step_draw + 1) : 1.f;
+      const bool lv = chain < p.step_Bl;          // (streams are indexed by the chain's place in the WHOLE batch)
+      scoin[tid] = lv ? philox_u01((uint64_t)(p.step_chain0 + chain), 2 * p.step_draw + 1) : 1.f;
+      su[tid] = lv ? philox_u01((uint64_t)(p.step_B + p.step_chain0 + chain), 2 * p.step_draw + 1) : 1.f;
     }
     __syncthreads();
     for (int i = tid; i < ROWS * (D / 4); i += kThreads4) {
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
       const int dsel = p.step_both ? (rr >= ROWS / 2 ? 1 : 0) : (scoin[k] > 0.5f ? 0 : 1);
       f32x4 xv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         xv = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
-        const uint64_t nb = (((uint64_t)dsel * (uint64_t)p.step_B + (uint64_t)chain) * D + c4) >> 2;
+        const uint64_t nb = (((uint64_t)dsel * (uint64_t)p.step_B + (uint64_t)(p.step_chain0 + chain)) * D + c4) >> 2;
         uint32_t c[4] = {(uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)(2 * p.step_draw), (uint32_t)((2 * p.step_draw) >> 32)};
         philox4x32_10(c, (uint32_t)p.step_seed, (uint32_t)(p.step_seed >> 32));
         float nv[4];
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
       const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
       f32x4 xin = {0.f, 0.f, 0.f, 0.f};
-      if (chain < p.step_B) xin = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
+      if (chain < p.step_Bl) xin = *reinterpret_cast<const f32x4*>(p.x0 + chain * D + c4);
       f32x4 xp;
       float pk;
       if (p.step_both) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
       *reinterpret_cast<f32x4*>(gin + k * SX + c4) = xin;
       *reinterpret_cast<f32x4*>(gout + k * SX + c4) = xo;
       if (c4 == 0) sobs[k * 4 + 3] = pk;
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         if (p.step_xprop) *reinterpret_cast<f32x4*>(p.step_xprop + chain * D + c4) = xp;
         if (p.step_xout) *reinterpret_cast<f32x4*>(p.step_xout + chain * D + c4) = xo;
         if (p.step_vprop) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
     const float inv2pi = 0.15915494309189533577f;
     if (tid < cpw) {
       const int64_t chain = (int64_t)blockIdx.x * cpw + tid;
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         const float q_in = sobs[tid * 4 + 1] * inv2pi, q_out = sobs[tid * 4 + 2] * inv2pi;
         if (p.step_px) p.step_px[chain] = sobs[tid * 4 + 3];
         if (p.step_act) p.step_act[chain] = (float)sites - sobs[tid * 4 + 0];
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
       if (tid == 0) {
         float a0 = 0.f, a1 = 0.f;
         for (int k = 0; k < cpw; ++k) {
-          if ((int64_t)blockIdx.x * cpw + k < p.step_B) {
+          if ((int64_t)blockIdx.x * cpw + k < p.step_Bl) {
             a0 += sobs[k * 4 + 3];
             a1 += fabsf(sobs[k * 4 + 1] * inv2pi - sobs[k * 4 + 2] * inv2pi);
           }
@@ -606,8 +606,8 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
           __syncthreads();
         }
         if (tid == 0) {
-          p.step_sums[0] = fin[0];
-          p.step_sums[1] = fin[kThreads4];
+          p.step_sums[0] = p.step_sums_acc ? p.step_sums[0] + fin[0] : fin[0];
+          p.step_sums[1] = p.step_sums_acc ? p.step_sums[1] + fin[kThreads4] : fin[kThreads4];
           p.step_sums[2] = (float)p.step_B;
           *reinterpret_cast<int*>(p.step_sums + 3) = 0;
         }
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
     for (int i = tid; p.step_x_next && i < cpw * (D / 4); i += kThreads4) {
       const int k = i / (D / 4), c4 = (i - k * (D / 4)) * 4;
       const int64_t chain = (int64_t)blockIdx.x * cpw + k;
-      if (chain < p.step_B) {
+      if (chain < p.step_Bl) {
         f32x4 w = *reinterpret_cast<const f32x4*>(gout + k * SX + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -1342,7 +1342,7 @@ def test_kept_products_equal_recomputed(la, L, arch, N, B):
 
 
 # ----------------------------------------------------------------- sub-tile form of the whole-trajectory kernel
-@pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536])
+@pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536, 2049, 2304, 3000, 4100])
 def test_subtile_form_equals_16_row_form(la, B):
     """Batches that cannot put a 16-row tile on every CU run the whole-trajectory kernel in its sub-tile form (4, 8 or 12
     rows per workgroup on v_mfma_f32_4x4x1_16B_f32, csrc/fused_traj4.hip).  Same k order, same epilogue expressions,
@@ -1352,7 +1352,7 @@ def test_subtile_form_equals_16_row_form(la, B):
     from l2hmc_amd import _lib, GaugeSampler
     T = X = 8
     N, eps, beta = 4, 0.2, 2.0
-    orc, _, dyn = _pair(T, X, N, eps, B, "mild", True)
+    orc, orc32, dyn = _pair(T, X, N, eps, B, "mild", True)
     rng = np.random.default_rng(21)
     x = torch.as_tensor(rng.uniform(0, 2 * np.pi, (B, 128)), dtype=torch.float32, device="cuda")
     v = torch.as_tensor(rng.standard_normal((B, 128)), dtype=torch.float32, device="cuda")
@@ -1383,6 +1383,7 @@ def test_subtile_form_equals_16_row_form(la, B):
     # same per-chain values (which are equal), so it agrees to fp32 rounding
     assert abs(outs[1][-1] - outs[0][-1]) <= 1e-6 * max(abs(outs[0][-1]), 1e-30) + 1e-12
     want = orc.transition_kernel(np_(x), beta, np_(v), forward=True)
+    f32 = orc32.transition_kernel(np_(x).astype(np.float32), beta, np_(v).astype(np.float32), forward=True)
     got = outs[1][10:14]
     assert H.relerr(np_(got[0]), want[0]) < 2 * TOL_OP and H.relerr(np_(got[1]), want[1]) < 2 * TOL_OP
-    assert np.abs(np_(got[2]) - want[2]).max() < TOL_P
+    assert np.abs(np_(got[2]) - want[2]).max() < max(TOL_P, P_RATIO * np.abs(f32[2] - want[2]).max())
