@@ -368,10 +368,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs c) {
 
 // =====================================================================
 // weight gradients: C[m][n] = sum_r P[r][m] * Q[r][n]   ("TN", contraction over rows)
-// 128 x 128 tile per workgroup, 16 rows per stage, fp32 32x32x2 MFMAs.  Tiles are staged exactly as
-// they lie in memory ([r][m]): the MFMA operand of lane (k, m) is then a single ds_read_b32 whose
-// 64 lanes hit 64 different banks (row stride 160 floats = 32 mod 64).  The contraction is split
-// over `splits` workgroups per tile; partials are summed in a fixed order afterwards.
+// 128 x 128 tile per workgroup, 16 rows per stage, fp32 32x32x2 MFMAs.  Tiles are staged TRANSPOSED
+// ([m][r], column stride 20 floats): the operands of lane (k-half, m) for four consecutive products are
+// one conflict-free ds_read_b128 (8 fragment reads per wave and stage instead of 32 four-byte ones).  The
+// contraction is split over `splits` workgroups per tile; partials are summed in a fixed order afterwards.
 // =====================================================================
 struct GemmTnArgs {
   const float* P; int ldp; int M;
@@ -388,8 +388,8 @@ struct GemmTnArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
-  constexpr int BM = 128, BN = 128, BKR = 16, LDT = 160;
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BKR * LDT];
+  constexpr int BM = 128, BN = 128, BKR = 16, LDK = BKR + 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BN * LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, r = lane & 31;
   const int tiles = p.mt * p.nt;
@@ -407,32 +407,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
   const int64_t rbeg = (int64_t)split * p.chunk;
   const int64_t rend = rbeg + p.chunk < p.R ? rbeg + p.chunk : p.R;
 
-  // staging: 16 rows x 32 16-byte chunks per operand = 512 chunks, 2 per thread
-  f32x4 rp[2], rq[2];
+  // staging: a thread owns a 4-row x 4-column block of ONE operand (threads 0..127: P, 128..255: Q): four 16-byte
+  // global loads (one per row; a wave's instruction covers 4 rows x 256 contiguous bytes), the 4 x 4 transpose is a
+  // renaming of registers, four 16-byte LDS stores.  Lane -> block: k-group (lane >> 2) & 3, column group
+  // 16 * (wave & 1) + 4 * (lane >> 4) + (lane & 3): the 16 lanes of an LDS phase then hold all 16 pairs
+  // (column group mod 4, k-group) = 16 different bank quads at column stride 20.
+  const bool isq = tid >= 128;
+  const int kg = (lane >> 2) & 3, cg = 16 * (wave & 1) + 4 * (lane >> 4) + (lane & 3);
+  const float* gsrc = isq ? p.Q : p.P;
+  const int ldg = isq ? p.ldq : p.ldp;
+  const int gcol = (isq ? n0 : m0) + 4 * cg;
+  const bool col_ok = gcol < (isq ? p.N : p.M);
+  // (Loads two stages ahead of the products -- two register slots, loop unrolled by two -- were measured: 164 VGPRs,
+  // two workgroups per CU instead of three, 295 -> 319 us per product.  One stage ahead it stays.)
+  f32x4 rg[4];
   auto load_stage = [&](int64_t rr) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 5, col = (c & 31) * 4;
-      const int64_t gr = rr + row;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-      if (gr < rend) {
-        if (m0 + col < p.M) a = *reinterpret_cast<const f32x4*>(p.P + gr * p.ldp + m0 + col);
-        if (n0 + col < p.N) b = *reinterpret_cast<const f32x4*>(p.Q + gr * p.ldq + n0 + col);
-      }
-      rp[i] = a;
-      rq[i] = b;
+    for (int i = 0; i < 4; ++i) {
+      const int64_t gr = rr + 4 * kg + i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (col_ok && gr < rend) a = *reinterpret_cast<const f32x4*>(gsrc + gr * ldg + gcol);
+      rg[i] = a;
     }
   };
   auto store_stage = [&](int buf) {
-    float* ps = lds + buf * 2 * BKR * LDT;
-    float* qs = ps + BKR * LDT;
+    float* dst = lds + buf * 2 * BN * LDK + (isq ? BN * LDK : 0) + (4 * cg) * LDK + 4 * kg;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 5, col = (c & 31) * 4;
-      *reinterpret_cast<f32x4*>(ps + row * LDT + col) = rp[i];
-      *reinterpret_cast<f32x4*>(qs + row * LDT + col) = rq[i];
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 c = {rg[0][j], rg[1][j], rg[2][j], rg[3][j]};
+      *reinterpret_cast<f32x4*>(dst + j * LDK) = c;
     }
   };
 
@@ -452,28 +455,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     for (int64_t rr = rbeg; rr < rend; rr += BKR) {
       const bool more = rr + BKR < rend;
       if (more) load_stage(rr + BKR);
-      const float* ps = lds + cur * 2 * BKR * LDT + wm * 64 + r;
-      const float* qs = lds + cur * 2 * BKR * LDT + BKR * LDT + wn * 64 + r;
-      // All 32 operands of the stage are fetched before its first product (counted lgkmcnt waits in between) rather
-      // than four at a time with a full wait per refill.  Measured: no change (5.78 -> 5.76 ms per training step) --
-      // the loop is not latency-bound.  tools/tn_loop_bench.hip takes it apart: MFMAs alone 143 TFLOP/s, + these LDS
-      // reads 126, + barrier 120, + stage stores and global loads 113 (this kernel: 113-115): every register a
-      // load writes costs the matrix pipe about four cycles, at any occupancy (cache-hot loads: no change either).
-      float av[BKR / 2][2], bv[BKR / 2][2];
+      const float* ps = lds + cur * 2 * BN * LDK + (wm * 64 + r) * LDK + 4 * half;
+      const float* qs = lds + cur * 2 * BN * LDK + BN * LDK + (wn * 64 + r) * LDK + 4 * half;
+      // The 8 operand fragments of the stage (16-byte reads: 4 contraction indices each) are fetched before its first
+      // product.  tools/tn_loop_bench.hip takes the loop apart (profiles/r03_tn_loop_bench.txt): MFMAs alone 143-147
+      // TFLOP/s, + these reads 130-132 (round 2: 32 four-byte reads from row-major tiles, 125-128), + barrier and stage
+      // stores 130-134, + the stage's global loads 116-121: every register a load writes costs the matrix pipe about
+      // four cycles at any occupancy.  In the training step: 294 -> 282 us per product on the same box.
+      f32x4 av[2][2], bv[2][2];
 #pragma unroll
-      for (int kk = 0; kk < BKR / 2; ++kk) {
-        const int k = 2 * kk + half;
-        av[kk][0] = ps[k * LDT]; av[kk][1] = ps[k * LDT + 32];
-        bv[kk][0] = qs[k * LDT]; bv[kk][1] = qs[k * LDT + 32];
+      for (int s = 0; s < 2; ++s) {
+        av[s][0] = *reinterpret_cast<const f32x4*>(ps + 8 * s);
+        av[s][1] = *reinterpret_cast<const f32x4*>(ps + 32 * LDK + 8 * s);
+        bv[s][0] = *reinterpret_cast<const f32x4*>(qs + 8 * s);
+        bv[s][1] = *reinterpret_cast<const f32x4*>(qs + 32 * LDK + 8 * s);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kk = 0; kk < BKR / 2; ++kk) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][0], bv[kk][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][0], bv[kk][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][1], bv[kk][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][1], bv[kk][1], acc[1][1], 0, 0, 0);
-      }
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                    // contraction indices 8 s + e (lanes 0..31), 8 s + 4 + e
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][0][e], bv[s][0][e], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][0][e], bv[s][1][e], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][1][e], bv[s][0][e], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][1][e], bv[s][1][e], acc[1][1], 0, 0, 0);
+        }
       if (more) store_stage(cur ^ 1);
       __syncthreads();
       cur ^= 1;

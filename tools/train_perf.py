@@ -10,6 +10,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import l2hmc_amd as la  # noqa: E402
 from l2hmc_amd.gauge_trainer import GaugeTrainer  # noqa: E402
+if os.environ.get("L2HMC_LIB"):          # a diagnostic build (e.g. the previous commit's library, for same-box before/after lines)
+    from l2hmc_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["L2HMC_LIB"])
 
 
 def main():
