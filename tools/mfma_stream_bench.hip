@@ -187,6 +187,73 @@ void run5(const char* name, const float* w, float* out, unsigned long long* cyc,
          ms, 2048.0 * nm * 2048 / ms / 1e9, 8.0 * nm / 32 * 8192 / ms / 1e6);
 }
 
+// mode 6: THIRTY-TWO rows per workgroup -- every weight fragment feeds two MFMAs (row groups 0 and 1), so the load
+// issue cost per MFMA halves; 16 accumulator tiles per wave, two A fragments per k-chunk from LDS.
+template <bool LDSA>
+__global__ __launch_bounds__(256) void bench6(const float* __restrict__ w, float* out, int nkc, int iters,
+                                              unsigned long long* cyc) {
+  __shared__ __attribute__((aligned(16))) float lds[32 * 520];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 32 * 520; i += 256) lds[i] = 0.001f * (i % 97);
+  __syncthreads();
+  f32x4 acc[2][NT];
+  for (int g = 0; g < 2; ++g)
+    for (int t = 0; t < NT; ++t) acc[g][t] = f32x4{0, 0, 0, 0};
+  const float* wp = w + (size_t)wave * nkc * NT * 256 + lane * 4;
+  const float* ap = lds + (lane & 15) * 520 + (lane >> 4) * 4;
+  f32x4 b[3][NT];
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    for (int s = 0; s < 3; ++s)
+      for (int t = 0; t < NT; ++t) b[s][t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)s * NT + t) * 256);
+    f32x4 a0 = f32x4{1.f, 0.5f, 0.25f, 0.125f}, a1 = f32x4{0.5f, 0.25f, 0.125f, 1.f};
+#pragma nounroll
+    for (int kc = 0; kc + 3 <= nkc; kc += 3) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (LDSA) {
+          a0 = *(const f32x4*)(ap + ((kc + s) & 31) * 16);
+          a1 = *(const f32x4*)(ap + 16 * 520 + ((kc + s) & 31) * 16);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b[s][t][e], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b[s][t][e], acc[1][t], 0, 0, 0);
+          }
+        if (kc + s + 3 < nkc)
+          for (int t = 0; t < NT; ++t) b[s][t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)(kc + s + 3) * NT + t) * 256);
+      }
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int g = 0; g < 2; ++g)
+    for (int t = 0; t < NT; ++t) s += acc[g][t][0] + acc[g][t][1] + acc[g][t][2] + acc[g][t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <bool LDSA>
+void run6(const char* name, const float* w, float* out, unsigned long long* cyc, int nkc, int iters) {
+  bench6<LDSA><<<256, 256>>>(w, out, nkc, 2, cyc);
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
+  bench6<LDSA><<<256, 256>>>(w, out, nkc, iters, cyc);
+  (void)hipEventRecord(e1);
+  (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(1024);
+  (void)hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost);
+  double sum = 0; for (auto v : h) sum += v;
+  const double nm = (double)iters * (nkc / 3 * 3) * 4 * NT * 2;
+  printf("%-70s nkc %3d: %.1f cyc/MFMA  %.3f ms  %.1f TFLOP/s  (%.0f GB/s per CU)\n", name, nkc, sum / 1024 / nm, ms,
+         1024.0 * nm * 2048 / ms / 1e9, 4.0 * nm / 64 * 8192 / ms / 1e6);
+}
+
 template <int MODE>
 void run(const char* name, const float* w, float* out, unsigned long long* cyc, int nkc, int iters, size_t stride) {
   bench<MODE><<<256, 256>>>(w, out, nkc, 2, cyc, stride);
@@ -224,6 +291,8 @@ int main() {
     run4<true>("mode 4: loads interleaved 1 per 4 MFMAs, A fragment from LDS", w, out, cyc, nkc, iters);
     run5<false>("mode 5: two waves per SIMD splitting K, A in registers", w, out, cyc, nkc, iters);
     run5<true>("mode 5: two waves per SIMD splitting K, A fragment from LDS", w, out, cyc, nkc, iters);
+    run6<false>("mode 6: 32 rows per workgroup (a weight fragment feeds 2 MFMAs), A in registers", w, out, cyc, nkc, iters);
+    run6<true>("mode 6: 32 rows per workgroup, both A fragments from LDS", w, out, cyc, nkc, iters);
   }
   return 0;
 }
