@@ -607,6 +607,35 @@ def main():
                 out["config"].setdefault("conv3D_arch", {})["error"] = repr(e)
                 failed.append("conv3D_arch")
 
+        # ---- the same dynamics at twice the chains per GPU: more than one round of 16-row workgroups, so the step
+        #      kernel runs in its 32-row form (csrc/fused_traj32.hip, every weight fragment feeds two MFMAs) ----
+        if rank == 0 and world == 1 and not args.no_roofline and both and not args.layered:
+            try:
+                B2 = 2 * BATCH
+                bdyn = build_gauge(3, B2, both)
+                bdyn.set_masks(dyn.mask.cpu().numpy())
+                bsmp = GaugeSampler(bdyn)
+                xb = torch.cat([x, x]).contiguous()
+                for _ in range(10):
+                    xb = bsmp.step(xb, beta)[0]
+                torch.cuda.synchronize()
+                tb0 = time.perf_counter()
+                for _ in range(20):
+                    xb = bsmp.step(xb, beta)[0]
+                torch.cuda.synchronize()
+                tbd = (time.perf_counter() - tb0) / 20
+                fl2 = 8.0 * net_macs(2 * c["L"] ** 2, 8 * c["L"] ** 2) * (2 * B2) * n_lf
+                out["config"]["twice_the_chains"] = {
+                    "what": f"{B2} chains on one GPU, same dynamics: gauge_traj_fused32_kernel (32 rows per workgroup), "
+                            "results bit-identical to the 16-row form",
+                    "ms_per_step": 1e3 * tbd, "chain_leapfrog_steps_per_s": B2 * n_lf / tbd,
+                    "whole_step_tflops": fl2 / tbd / 1e12, "whole_step_frac": fl2 / tbd / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                bsmp.stats.wait()
+                del bdyn, bsmp, xb
+            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
+                out["config"]["twice_the_chains"] = {"error": repr(e)}
+                failed.append("twice_the_chains")
+
         # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
         #      takes part because the gradient bucket is all-reduced (f1/f2) ----
         if not args.no_train:

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libl2hmc_hip.so")
-SOURCES = ["capi.hip", "u1_lattice.hip", "stq_dense.hip", "leapfrog.hip", "small_mlp.hip", "fused_traj.hip", "fused_traj4.hip",
+SOURCES = ["capi.hip", "u1_lattice.hip", "stq_dense.hip", "leapfrog.hip", "small_mlp.hip", "fused_traj.hip", "fused_traj4.hip", "fused_traj32.hip",
            "conv3d_front.hip", "mcmc_step.hip", "loss.hip", "train.hip", "small_train.hip", "fused_train.hip"]
 # every header is a dependency of every object (coarse, but never stale)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "l2hmc_hip.h")]

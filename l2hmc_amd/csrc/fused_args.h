@@ -47,4 +47,9 @@ int launch_fused4_pack(const l2hmc_dense_net* n, float* image4, hipStream_t stre
 int fused4_rows_per_wg(int64_t rows);                                // 0: use the 16-row form; else 4 or 8
 int launch_fused4(const FusedArgs& a, int rows_per_wg, hipStream_t stream);
 
+// the 32-row form (fused_traj32.hip): same plans, same packed image as the 16-row form; for batches of more than one
+// round of 16-row workgroups (each weight fragment then feeds two MFMAs)
+int fused32_supported(const l2hmc_dense_net* n);
+int launch_fused32(const FusedArgs& a, hipStream_t stream);
+
 }  // namespace l2hmc

@@ -1021,8 +1021,11 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.stagger = g_fused_stagger;
 #endif
   // batches that cannot put a 16-row tile on every CU: the sub-tile form (4 or 8 rows per workgroup, same bits)
-  if (!conv && !tape && subtile_enabled())
+  if (!conv && !tape && subtile_enabled()) {
     if (const int rpw = fused4_rows_per_wg(rows)) return launch_fused4(a, rpw, stream);
+    // more than one round of 16-row workgroups: the 32-row form (each weight fragment feeds two MFMAs)
+    if (rows > (int64_t)kFM * device_cu_count()) return launch_fused32(a, stream);
+  }
   const dim3 grid((unsigned)ceil_div(rows, kFM));
   prof_before(kProfFused, stream);
   if (conv && tape)
@@ -1061,23 +1064,39 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
     step_once.done();
   }
   L2HMC_REQUIRE(x_in && (x_next || x_out) && B > 0 && (!step_sums || part), "fused step: bad arguments");
-  // Which form runs which chains.  The 16-row form covers 16 * (number of CUs) rows per round of workgroups, so a
-  // batch one chain past a round costs a whole further round; the sub-tile form (fused_traj4.hip: 4 / 8 / 12 rows
-  // per workgroup, same arithmetic per row, same bits) takes a batch that is small as a whole, or the remainder of
-  // a large one in a second launch on the same stream (chains [b_main, B): global chain indices for the Philox
-  // streams, pointers moved to the first chain of the part, the step's sums added to the first launch's).
+  // Which form runs which chains (GenericNet 8x8 plans; all forms give the same bits).  The 16-row form covers
+  // 16 * (number of CUs) rows per round of workgroups (1.58 ms at the benchmark dynamics), so a batch one chain past a
+  // round costs a whole further round.  The batch is cut into at most three parts, launched one after the other on the
+  // same stream (a part: chains [c0, c0 + n), global chain indices for the Philox streams, pointers moved to its first
+  // chain, the step's sums added to the earlier parts'):
+  //   - whole rounds of 32-row workgroups (fused_traj32.hip: twice the rows of a 16-row round in 1.87 x its time);
+  //   - what is left: nothing / a sub-tile launch (fused_traj4.hip: up to 3072 rows in 0.9-1.5 ms) / one 16-row round /
+  //     a 16-row round and a sub-tile launch (when the rest beyond the round is small) / one more 32-row round;
+  //   - a batch that is small as a whole is one sub-tile launch, a batch of at most one round one 16-row launch.
   const int ndir = both ? 2 : 1;
-  int64_t b_main = B;
-  int rpw_tail = 0;
-  if (!conv && subtile_enabled()) {
-    const int all = fused4_rows_per_wg(B * ndir);
-    if (all) {
-      b_main = 0; rpw_tail = all;
+  struct Part { int64_t rows; int rpw; };
+  Part parts[3];
+  int nparts = 0;
+  const int64_t rows_all = B * ndir;
+  if (conv || !subtile_enabled()) {
+    parts[nparts++] = {rows_all, kFM};
+  } else if (const int all = fused4_rows_per_wg(rows_all)) {
+    parts[nparts++] = {rows_all, all};
+  } else {
+    const int64_t round16 = (int64_t)kFM * device_cu_count();            // rows in one full round of 16-row workgroups
+    const int64_t main32 = rows_all / (2 * round16) * (2 * round16), rem = rows_all - main32;
+    const int64_t over = rem - round16;                                  // rows beyond one more 16-row round
+    if (rem > round16 && !(over <= 2048 && fused4_rows_per_wg(over))) {
+      parts[nparts++] = {rows_all, 32};                                  // the rest fills most of another 32-row round
     } else {
-      const int64_t round = (int64_t)kFM * device_cu_count() / ndir;     // chains in one full round of 16-row workgroups
-      const int64_t full = B / round * round;
-      const int r = (full > 0 && B > full) ? fused4_rows_per_wg((B - full) * ndir) : 0;
-      if (r) { b_main = full; rpw_tail = r; }
+      if (main32 > 0) parts[nparts++] = {main32, 32};
+      if (rem > round16) {
+        parts[nparts++] = {round16, kFM};
+        parts[nparts++] = {over, fused4_rows_per_wg(over)};
+      } else if (rem > 0) {
+        const int sub = fused4_rows_per_wg(rem);
+        parts[nparts++] = {rem, sub ? sub : kFM};
+      }
     }
   }
   auto part_of = [&](int64_t c0, int64_t nb, int rpw, int accumulate) {
@@ -1104,8 +1123,7 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
 #endif
     return a;
   };
-  if (b_main > 0) {
-    FusedArgs a = part_of(0, b_main, kFM, 0);
+  auto launch16 = [&](const FusedArgs& a) {
     const unsigned nwg = (unsigned)(a.rows / kFM);
     prof_before(kProfFused, stream);
     if (conv)
@@ -1114,10 +1132,16 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
       hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), dim3(nwg), dim3(CfgG::THREADS), lds, stream, a);
     prof_after(kProfFused, stream);
     L2HMC_CHECK_LAUNCH("gauge_traj_fused (step)");
-  }
-  if (rpw_tail) {
-    FusedArgs a = part_of(b_main, B - b_main, rpw_tail, b_main > 0);
-    return launch_fused4(a, rpw_tail, stream);
+    return L2HMC_OK;
+  };
+  int64_t c0 = 0;
+  for (int i = 0; i < nparts; ++i) {
+    const int64_t nb = parts[i].rows / ndir;                             // (every cut is at an even row count)
+    const FusedArgs a = part_of(c0, nb, parts[i].rpw, i > 0);
+    if (int e = parts[i].rpw == 32 ? launch_fused32(a, stream)
+                : parts[i].rpw == kFM ? launch16(a) : launch_fused4(a, parts[i].rpw, stream))
+      return e;
+    c0 += nb;
   }
   return L2HMC_OK;
 }

@@ -13,7 +13,7 @@
 // network/generic_net.py:129-146): a product's k runs in the order the 16-row form's instructions take it (within a
 // 16-k chunk: k = 4 q + e for e = 0..3, q = 0..3), epilogue expressions are the same, the log-det partial sums are added
 // in the same grouping, the Philox streams are indexed by chain -- the results are bit-identical to the 16-row form
-// (tests/test_gpu_parity.py::test_subtile_form_equals_16_row_form).
+// (tests/test_gpu_parity.py::test_subtile_and_32_row_forms_equal_16_row_form).
 //
 // Geometry: 4 waves; wave w owns output columns [128 w, 128 w + 128) of layers 1 / 2 (two 64-column blocks) and columns
 // [32 w, 32 w + 32) of each head (block 0: lanes 0-31 S, lanes 32-63 T; block 1: lanes 0-31 Q); a lane ends up with ONE

@@ -1342,9 +1342,12 @@ def test_kept_products_equal_recomputed(la, L, arch, N, B):
 
 
 # ----------------------------------------------------------------- sub-tile form of the whole-trajectory kernel
-@pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536, 2049, 2304, 3000, 4100])
-def test_subtile_form_equals_16_row_form(la, B):
-    """Batches that cannot put a 16-row tile on every CU run the whole-trajectory kernel in its sub-tile form (4, 8 or 12
+@pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536, 2049, 2304, 3000, 3600, 4096, 4100, 5000, 6000, 6200])
+def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
+    """Batches of more than one round of 16-row workgroups run in the 32-row form (csrc/fused_traj32.hip: every weight
+    fragment feeds two MFMAs), cut into up to three launches with a 16-row round and / or a sub-tile launch for the rest
+    (launch_fused_step: 3600 and 4096 chains one 32-row launch, 2049 / 3000: 16-row + sub-tile, 4100 / 5000: 32-row +
+    sub-tile, 6000: 32-row + 16-row, 6200: all three).  Batches that cannot put a 16-row tile on every CU run the whole-trajectory kernel in its sub-tile form (4, 8 or 12
     rows per workgroup on v_mfma_f32_4x4x1_16B_f32, csrc/fused_traj4.hip).  Same k order, same epilogue expressions,
     same grouping of every sum, same Philox indexing: a whole MCMC step, the trajectories alone (both directions, per-row
     directions) and single leapfrog steps must EQUAL the 16-row form bit for bit; and the sub-tile form agrees with

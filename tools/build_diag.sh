@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../l2hmc_amd/csrc"
 for NW in ${DIAG_WAVES_LIST:-4}; do
   OUT=../../tools/_diag/w$NW
   mkdir -p $OUT
-  for f in capi u1_lattice stq_dense leapfrog small_mlp fused_traj fused_traj4 conv3d_front mcmc_step loss train small_train fused_train; do
+  for f in capi u1_lattice stq_dense leapfrog small_mlp fused_traj fused_traj4 fused_traj32 conv3d_front mcmc_step loss train small_train fused_train; do
     ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DL2HMC_STAMPS -DL2HMC_FUSED_WAVES=$NW $EXTRA -c $f.hip -o $OUT/$f.o || touch $OUT/FAILED ) &
   done
   wait
