@@ -1042,6 +1042,45 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
 }
 
 // One launch = one whole MCMC step of B chains (see FusedArgs::step_*).  part: 2 * ceil(B / cpw) floats of scratch.
+// The launches of one MCMC step over `rows_all` chain-rows (see launch_fused_step): at most three {rows, rows per
+// workgroup} parts, every cut at an even row count.  forms = the sub-tile and 32-row forms may be used.
+struct StepPart { int64_t rows; int rpw; };
+static int plan_step_parts(int64_t rows_all, bool forms, int cus, StepPart (&parts)[3]) {
+  int n = 0;
+  if (!forms) {
+    parts[n++] = {rows_all, kFM};
+  } else if (const int all = fused4_rows_per_wg(rows_all)) {
+    parts[n++] = {rows_all, all};
+  } else {
+    const int64_t round16 = (int64_t)kFM * cus;                          // rows in one full round of 16-row workgroups
+    const int64_t main32 = rows_all / (2 * round16) * (2 * round16), rem = rows_all - main32;
+    const int64_t over = rem - round16;                                  // rows beyond one more 16-row round
+    if (rem > round16 && !(over <= 2048 && fused4_rows_per_wg(over))) {
+      parts[n++] = {rows_all, 32};                                       // the rest fills most of another 32-row round
+    } else {
+      if (main32 > 0) parts[n++] = {main32, 32};
+      if (rem > round16) {
+        parts[n++] = {round16, kFM};
+        parts[n++] = {over, fused4_rows_per_wg(over)};
+      } else if (rem > 0) {
+        const int sub = fused4_rows_per_wg(rem);
+        parts[n++] = {rem, sub ? sub : kFM};
+      }
+    }
+  }
+  return n;
+}
+// test hook (host logic only, no device call; include/ does not declare it): the plan for `rows_all` rows on `cus` CUs
+extern "C" int l2hmc_debug_step_plan(int64_t rows_all, int cus, int64_t* rows_out, int* rpw_out) {
+  StepPart parts[3];
+  const int n = plan_step_parts(rows_all, true, cus, parts);
+  for (int i = 0; i < n; ++i) {
+    rows_out[i] = parts[i].rows;
+    rpw_out[i] = parts[i].rpw;
+  }
+  return n;
+}
+
 int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, float* x_next, int64_t B,
                       uint64_t seed, uint64_t draw, int both, float* px, float* actions, float* plaqs, float* charges,
                       float* dq, float* step_sums, float* part, hipStream_t stream, float* x_prop, float* v_prop,
@@ -1074,31 +1113,8 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
   //     a 16-row round and a sub-tile launch (when the rest beyond the round is small) / one more 32-row round;
   //   - a batch that is small as a whole is one sub-tile launch, a batch of at most one round one 16-row launch.
   const int ndir = both ? 2 : 1;
-  struct Part { int64_t rows; int rpw; };
-  Part parts[3];
-  int nparts = 0;
-  const int64_t rows_all = B * ndir;
-  if (conv || !subtile_enabled()) {
-    parts[nparts++] = {rows_all, kFM};
-  } else if (const int all = fused4_rows_per_wg(rows_all)) {
-    parts[nparts++] = {rows_all, all};
-  } else {
-    const int64_t round16 = (int64_t)kFM * device_cu_count();            // rows in one full round of 16-row workgroups
-    const int64_t main32 = rows_all / (2 * round16) * (2 * round16), rem = rows_all - main32;
-    const int64_t over = rem - round16;                                  // rows beyond one more 16-row round
-    if (rem > round16 && !(over <= 2048 && fused4_rows_per_wg(over))) {
-      parts[nparts++] = {rows_all, 32};                                  // the rest fills most of another 32-row round
-    } else {
-      if (main32 > 0) parts[nparts++] = {main32, 32};
-      if (rem > round16) {
-        parts[nparts++] = {round16, kFM};
-        parts[nparts++] = {over, fused4_rows_per_wg(over)};
-      } else if (rem > 0) {
-        const int sub = fused4_rows_per_wg(rem);
-        parts[nparts++] = {rem, sub ? sub : kFM};
-      }
-    }
-  }
+  StepPart parts[3];
+  const int nparts = plan_step_parts(B * ndir, !conv && subtile_enabled(), device_cu_count(), parts);
   auto part_of = [&](int64_t c0, int64_t nb, int rpw, int accumulate) {
     const int cpw = both ? rpw / 2 : rpw;
     const int64_t D = 2 * (int64_t)p->T * p->X;

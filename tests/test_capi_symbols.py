@@ -140,3 +140,39 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(tmp_path, "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_step_launch_plan_covers_every_batch(L):
+    """launch_fused_step (csrc/fused_traj.hip) cuts the chain-rows of one MCMC step into at most three launches:
+    whole rounds of 32-row workgroups, one 16-row round, a sub-tile launch.  Host logic only: every plan covers its
+    rows exactly once, cuts at even row counts (both directions of a chain stay in one workgroup), uses the
+    sub-tile form only where it has a workgroup per CU or fewer, and never needs more rounds than 16-row tiles
+    alone would."""
+    fn = L.l2hmc_debug_step_plan
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    rows_out, rpw_out = (C.c_int64 * 3)(), (C.c_int * 3)()
+    cus = 256
+    t16, t32 = 1.0, 1.8                                   # one round of 16-row / 32-row workgroups (measured 1.59 / 2.86 ms)
+
+    def cost(rows, rpw):
+        if rpw == 16:
+            return t16 * -(-rows // (16 * cus))
+        if rpw == 32:
+            return t32 * -(-rows // (32 * cus))
+        return {4: 0.58, 8: 0.68, 12: 0.93}[rpw]          # sub-tile launches (0.91 / 1.07 / 1.46 ms)
+    for rows in list(range(2, 40000, 2)) + [1, 3, 4097, 8193, 1 << 20, (1 << 20) + 2]:
+        n = fn(rows, cus, rows_out, rpw_out)
+        parts = [(rows_out[i], rpw_out[i]) for i in range(n)]
+        assert 1 <= n <= 3 and sum(r for r, _ in parts) == rows, (rows, parts)
+        assert all(r > 0 and w in (4, 8, 12, 16, 32) for r, w in parts), (rows, parts)
+        assert all(r % 2 == 0 for r, _ in parts[:-1]), (rows, parts)
+        for r, w in parts:
+            if w < 16:
+                assert r <= w * cus, (rows, parts)
+            if w == 32:
+                assert r > 16 * cus, (rows, parts)
+        assert sum(cost(r, w) for r, w in parts) <= t16 * -(-rows // (16 * cus)) + 1e-9, (rows, parts)
+    assert [(rows_out[i], rpw_out[i]) for i in range(fn(4096, cus, rows_out, rpw_out))] == [(4096, 16)]
+    assert [(rows_out[i], rpw_out[i]) for i in range(fn(8192, cus, rows_out, rpw_out))] == [(8192, 32)]
+    assert [(rows_out[i], rpw_out[i]) for i in range(fn(12400, cus, rows_out, rpw_out))] == [(8192, 32), (4096, 16), (112, 4)]
