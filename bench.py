@@ -631,6 +631,17 @@ def main():
                     "ms_per_step": 1e3 * tbd, "chain_leapfrog_steps_per_s": B2 * n_lf / tbd,
                     "whole_step_tflops": fl2 / tbd / 1e12, "whole_step_frac": fl2 / tbd / 1e12 / PEAK_F32_MFMA_TFLOPS}
                 bsmp.stats.wait()
+
+                def run2():
+                    xs = xb
+                    for _ in range(20):
+                        xs = bsmp.step(xs, beta)[0]
+                us2, n2 = profile_class(_lib.lib(), 5, run2, _lib)       # HIP events on the launch stream
+                bsmp.stats.wait()
+                if n2:
+                    out["config"]["twice_the_chains"].update(
+                        kernel_avg_us=us2, kernel_launches=n2, kernel_tflops=fl2 / (us2 * 1e-6) / 1e12,
+                        kernel_frac=fl2 / (us2 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS)
                 del bdyn, bsmp, xb
             except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
                 out["config"]["twice_the_chains"] = {"error": repr(e)}
