@@ -388,6 +388,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
@@ -473,24 +474,25 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const float* as = lds + cur * STAGE + (wave * 16 + r) * LDK + q * 4;
-    const float* bs = lds + cur * STAGE + BM * LDK + r * LDK + q * 4;
+    // wave (wm, wn): rows [32 wm, 32 wm + 32) x columns [16 wn, 16 wn + 16) of all three heads -- per 16 k two row
+    // fragments and three column fragments feed 24 MFMAs (5 ds_read_b128; a wave owning 16 rows x all 96 columns
+    // read 7)
+    const float* as = lds + cur * STAGE + (wm * 32 + r) * LDK + q * 4;
+    const float* bs = lds + cur * STAGE + BM * LDK + (wn * 16 + r) * LDK + q * 4;
 #pragma unroll
     for (int kh = 0; kh < BK / 16; ++kh) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(as + kh * 16);
-      f32x4 bf[3][2];
+      f32x4 af[2], bf[3];
 #pragma unroll
-      for (int h = 0; h < 3; ++h)
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + kh * 16);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bf[h][j] = *reinterpret_cast<const f32x4*>(bs + (h * 32 + j * 16) * LDK + kh * 16);
+      for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + kh * 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[h][j][e], acc[h][j], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+            acc[h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[h][e], acc[h][i], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
@@ -498,26 +500,43 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 
   L2HMC_STAMP(2);
   // --- epilogue.  C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
-  float ld[4] = {0.f, 0.f, 0.f, 0.f};
+  // acc[h][i]: rows m0 + 32 wm + 16 i + 4 q + e, column n0 + 16 wn + r
+  const int col = n0 + wn * 16 + r;
+  const bool cok = col < p.D;
+  const HeadsCol c = heads_col(p, col, cok);
+  float ld[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + j * 16 + r;
-    const bool cok = col < p.D;
-    const HeadsCol c = heads_col(p, col, cok);
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t row = m0 + wave * 16 + q * 4 + e;
+      const int64_t row = m0 + wm * 32 + i * 16 + q * 4 + e;
       if (row >= p.rows || !cok) continue;
-      ld[e] += heads_element(p, c, row, col, acc[0][j][e], acc[1][j][e], acc[2][j][e]);
+      ld[i][e] = heads_element(p, c, row, col, acc[0][i][e], acc[1][i][e], acc[2][i][e]);
     }
-  }
   if (p.mode != kHeadsMaterialise && p.ld_part) {
-    // reduce over the 16 lanes (columns) of each quarter; rows q*4+e stay apart
+    // a row's 32 columns of this workgroup sit in two waves (wn = 0, 1): each reduces its 16 lanes, the second hands
+    // its sums over through LDS (the stage buffers are free), the first adds them in a fixed order
+    float t[2][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float t = row16_sum(ld[e]);        // DPP on the VALU (four __shfl_xor would be ds_bpermute round trips)
-      const int64_t row = m0 + wave * 16 + q * 4 + e;
-      if (r == 0 && row < p.rows) p.ld_part[row * p.ncb + nt_id] += t;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[i][e] = row16_sum(ld[i][e]);   // DPP on the VALU
+    float* hand = lds;                                    // [wm][32 rows]
+    if (wn == 1 && r == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hand[wm * 32 + i * 16 + q * 4 + e] = t[i][e];
+    }
+    __syncthreads();
+    if (wn == 0 && r == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t row = m0 + wm * 32 + i * 16 + q * 4 + e;
+          if (row < p.rows) p.ld_part[row * p.ncb + nt_id] += t[i][e] + hand[wm * 32 + i * 16 + q * 4 + e];
+        }
     }
   }
   L2HMC_STAMP(3);
