@@ -548,13 +548,15 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 // workgroup on 32x32x2 MFMAs.  Wave (wm, wn) owns 64 rows x 32 columns of ALL THREE heads (S, T, Q of an element
 // still share a lane): per 8 k it reads 2 + 3 fragments for 24 MFMAs of 64 cycles -- 0.10 ds_read_b128 per 1024
 // multiply-adds against 0.29 in heads_kernel (7 reads per 24 MFMAs of 32 cycles), which is what held that kernel
-// at 0.73 of the MFMA rate where the same-shape hidden layer reaches 0.86.  k-tiles of 16 (row stride 20 floats:
-// the two 16-lane groups of a ds_read_b128 hit 16 distinct 4-bank slots) keep the double buffer at 51 KB, so two
-// workgroups share a CU with independent barriers.
+// at 0.73 of the MFMA rate where the same-shape hidden layer reaches 0.86.  k-tiles of 16 keep the double buffer at
+// 41 KB, so two workgroups share a CU with independent barriers.  Rows are stored without padding and the four
+// 16-byte chunks of row R are XOR-swizzled with (R >> 2) & 3: the staging stores (4 rows x 4 chunks per 16 lanes) and
+// the fragment reads (16 rows, one chunk) both touch 16 distinct 4-bank slots.  (Round 3 began with row stride 20:
+// SQ_LDS_BANK_CONFLICT = a third of the LDS-active cycles, from the stores.)
 // =====================================================================
 __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   constexpr int BM = 128, BNH = 64, NB = 3 * BNH, BK = 16;
-  constexpr int CPR = BK / 4, LDK = BK + 4;
+  constexpr int CPR = BK / 4, LDK = BK;              // no pad: 16-byte chunk j of row R sits at slot j ^ ((R >> 2) & 3)
   constexpr int A_CH = BM * CPR / kGemmThreads;      // 2
   constexpr int B_CH = NB * CPR / kGemmThreads;      // 3
   constexpr int STAGE = (BM + NB) * LDK;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
     const int row = c / CPR, kc = (c % CPR) * 4;
     const int64_t g = (m0 + row) < p.rows ? m0 + row : p.rows - 1;
     a_src[i] = p.A + g * p.lda + kc;
-    a_off[i] = row * LDK + kc;
+    a_off[i] = row * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
   const float* b_src[B_CH];
   int b_off[B_CH];
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
     const int hd = row >> 6, nn = row & 63;
     const int col = (n0 + nn) < p.D ? n0 + nn : p.D - 1;
     b_src[i] = p.Wt + ((int64_t)hd * p.D + col) * p.K + kc;
-    b_off[i] = (BM + row) * LDK + kc;
+    b_off[i] = (BM + row) * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
   f32x4 ra[A_CH], rb[B_CH];
   auto load_tile = [&](int kt) {
@@ -622,15 +624,18 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const float* as = lds + cur * STAGE + (wm * 64 + r) * LDK + half * 4;
-    const float* bs = lds + cur * STAGE + (BM + wn * 32 + r) * LDK + half * 4;
+    // (every row offset below is a multiple of 32, so the swizzle term (row >> 2) & 3 is that of r alone)
+    const int sw = (r >> 2) & 3;
+    const float* as = lds + cur * STAGE + (wm * 64 + r) * LDK;
+    const float* bs = lds + cur * STAGE + (BM + wn * 32 + r) * LDK;
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
+      const int slot = ((2 * kq + half) ^ sw) << 2;
       f32x4 af[2], bf[3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + kq * 8);
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + slot);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * BNH * LDK + kq * 8);
+      for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * BNH * LDK + slot);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
