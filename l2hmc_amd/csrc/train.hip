@@ -408,10 +408,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
   const int64_t rend = rbeg + p.chunk < p.R ? rbeg + p.chunk : p.R;
 
   // staging: a thread owns a 4-row x 4-column block of ONE operand (threads 0..127: P, 128..255: Q): four 16-byte
-  // global loads (one per row; a wave's instruction covers 4 rows x 256 contiguous bytes), the 4 x 4 transpose is a
+  // global loads (one per row; 16 consecutive lanes cover 256 contiguous bytes of a row), the 4 x 4 transpose is a
   // renaming of registers, four 16-byte LDS stores.  Lane -> block: k-group (lane >> 2) & 3, column group
-  // 16 * (wave & 1) + 4 * (lane >> 4) + (lane & 3): the 16 lanes of an LDS phase then hold all 16 pairs
-  // (column group mod 4, k-group) = 16 different bank quads at column stride 20.
+  // 16 * (wave & 1) + 4 * (lane >> 4) + (lane & 3).  The fragment reads (ds_read_b128: four groups of 16 lanes, banks
+  // modulo 64) see 16 columns of one k-group at column stride 20: slot 5 c (mod 16), all different.  The stores
+  // (ds_write_b128: groups of 8 consecutive lanes, banks modulo 32) are 2-way conflicted with this mapping
+  // (SQ_LDS_BANK_CONFLICT = a third of the LDS-active cycles); the conflict-free mapping -- k-group lane & 3, column
+  // group lane >> 2 -- was measured: 281 -> 283 us per product (a store is bound by moving its registers to the LDS,
+  // 13 cycles, not by the array, and consecutive lanes then load from four different rows).  This one stays.
   const bool isq = tid >= 128;
   const int kg = (lane >> 2) & 3, cg = 16 * (wave & 1) + 4 * (lane >> 4) + (lane & 3);
   const float* gsrc = isq ? p.Q : p.P;
