@@ -213,19 +213,36 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           if (nstep >= 0) load_tape(2 * nstep + (ncall >= 2 ? 1 : 0), ncall == 0 || ncall == 3, tnext);
         }
         float o_s[8], o_t[8], o_q[8];
+        // The thread's 8 columns of every LDS row it touches move as two 16-byte pieces (scalar accesses at a column
+        // stride of 8 floats between lanes are 8-way bank conflicts: SQ_LDS_BANK_CONFLICT was 56 % of this kernel's
+        // LDS-active cycles), the element-wise arithmetic runs on registers.
+        float udx[8], udv[8], mfr[8], mbr[8], ecsr[8], ecqr[8], dgdr[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(dxs + fc * SX + c0 + 4 * h);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(dvs + fc * SX + c0 + 4 * h);
+          const f32x4 a2 = *reinterpret_cast<const f32x4*>(skm + c0 + 4 * h);
+          const f32x4 a3 = *reinterpret_cast<const f32x4*>(skm + D + c0 + 4 * h);
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(ecs + c0 + 4 * h);
+          const f32x4 a5 = *reinterpret_cast<const f32x4*>(ecq + c0 + 4 * h);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            udx[4 * h + k] = a0[k]; udv[4 * h + k] = a1[k]; mfr[4 * h + k] = a2[k]; mbr[4 * h + k] = a3[k];
+            ecsr[4 * h + k] = a4[k]; ecqr[4 * h + k] = a5[k]; dgdr[4 * h + k] = 0.f;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int c = c0 + k;
           const float eq = fast_exp(eps * Q[k]);
           float dS, dT, dQ;
           if (is_v) {
             // st = v before the kick, ib = force, ia = x
-            const float vv = st[k], gg = ib[k], u = dvs[fc * SX + c], he = 0.5f * eps;
+            const float vv = st[k], gg = ib[k], u = udv[k], he = 0.5f * eps;
             float dgd;
             if (!d) {
               const float es = fast_exp(he * S[k]);
               const float ds = u * vv * es + dl;
-              dvs[fc * SX + c] = u * es;
+              udv[k] = u * es;
               dS = ds * he; dT = u * he; dQ = -u * he * eq * gg * eps;
               dgd = -u * he * eq;
               deps += ds * 0.5f * S[k] - u * 0.5f * (eq * gg - Tt[k]) - u * he * gg * eq * Q[k];
@@ -234,24 +251,23 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
               const float vp = es * (vv + he * (eq * gg - Tt[k]));
               const float dw = u * es;
               const float ds = u * vp + dl;
-              dvs[fc * SX + c] = dw;
+              udv[k] = dw;
               dS = -he * ds; dT = -dw * he; dQ = dw * he * eq * gg * eps;
               dgd = dw * he * eq;
               deps += -0.5f * S[k] * ds + dw * 0.5f * (eq * gg - Tt[k]) + dw * he * gg * eq * Q[k];
             }
-            us[fc * SX + c] = dgd;
-            xs[fc * SX + c] = ia[k];
+            dgdr[k] = dgd;
           } else {
             // st = x before the update, ia = v; keep mask per direction and sub-update
-            const float mf = skm[c], mb = skm[D + c];
+            const float mf = mfr[k], mb = mbr[k];
             const float kk = sub == 0 ? (d ? 1.f - mb : mf) : (d ? mb : 1.f - mf), mi = 1.f - kk;
-            const float xx = st[k], vv = ia[k], u = dxs[fc * SX + c];
+            const float xx = st[k], vv = ia[k], u = udx[k];
             const float dy = mi * u;
             if (!d) {
               const float es = fast_exp(eps * S[k]);
               const float ds = dy * xx * es + dl * mi;
-              dxs[fc * SX + c] = kk * u + dy * es;
-              dvs[fc * SX + c] += dy * eps * eq;
+              udx[k] = kk * u + dy * es;
+              udv[k] += dy * eps * eq;
               dS = eps * ds; dT = dy * eps; dQ = dy * eps * eq * vv * eps;
               deps += ds * S[k] + dy * (eq * vv + Tt[k]) + dy * eps * vv * eq * Q[k];
             } else {
@@ -259,14 +275,14 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
               const float w = xx - eps * (eq * vv + Tt[k]);
               const float dw = dy * es;
               const float ds = dy * (es * w) + dl * mi;
-              dxs[fc * SX + c] = kk * u + dw;
-              dvs[fc * SX + c] -= dw * eps * eq;
+              udx[k] = kk * u + dw;
+              udv[k] -= dw * eps * eq;
               dS = -eps * ds; dT = -dw * eps; dQ = -dw * eps * eq * vv * eps;
               deps += -S[k] * ds - dw * (eq * vv + Tt[k]) - dw * eps * vv * eq * Q[k];
             }
           }
           // through tanh(.) * exp(coeff) (generic_net.py:139-144)
-          const float es_ = ecs[c], eq_ = ecq[c];
+          const float es_ = ecsr[k], eq_ = ecqr[k];
           const float th = S[k] / es_;
           float daq = dQ * eq_;
           if (q_tanh) {
@@ -278,6 +294,20 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
           o_q[k] = daq;
           if (is_v) { acs_v[k] += dS * S[k]; acq_v[k] += dQ * Q[k]; }
           else { acs_x[k] += dS * S[k]; acq_x[k] += dQ * Q[k]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<f32x4*>(dvs + fc * SX + c0 + 4 * h) =
+              f32x4{udv[4 * h], udv[4 * h + 1], udv[4 * h + 2], udv[4 * h + 3]};
+          if (is_v) {
+            *reinterpret_cast<f32x4*>(us + fc * SX + c0 + 4 * h) =
+                f32x4{dgdr[4 * h], dgdr[4 * h + 1], dgdr[4 * h + 2], dgdr[4 * h + 3]};
+            *reinterpret_cast<f32x4*>(xs + fc * SX + c0 + 4 * h) =
+                f32x4{ia[4 * h], ia[4 * h + 1], ia[4 * h + 2], ia[4 * h + 3]};
+          } else {
+            *reinterpret_cast<f32x4*>(dxs + fc * SX + c0 + 4 * h) =
+                f32x4{udx[4 * h], udx[4 * h + 1], udx[4 * h + 2], udx[4 * h + 3]};
+          }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
