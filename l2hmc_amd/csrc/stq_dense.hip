@@ -53,7 +53,7 @@ __device__ __forceinline__ float l1_preact(float acc, float bj, float tc, float 
 // check and the k-loop runs over ceil(K / BK) zero-padded tiles -- the same arithmetic (zeros add nothing), a
 // slower load path that only odd shapes take.
 template <int BM, int KIND, int BK, int BN = 128, bool RAGGED = false>
-__global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p) {
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int CPR = BK / 4;              // 16-byte chunks per staged row
   constexpr int LDK = BK + 4;              // rows of 36 / 68 floats: an odd number of 16-B slots => conflict-free b128 reads
   constexpr int MT = BM / 64;              // 32x32 tiles per wave along M (wave grid 2 x 2)
@@ -191,19 +191,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_relu_kernel(GemmReluArgs p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // raw accumulators <-> [rows][N] in the C layout of the 32x32 MFMA (a lane's 32-column run is 128 contiguous bytes)
+  // raw accumulators <-> [rows][N] in the C layout of the 32x32 MFMA (a lane's 32-column run is 128 contiguous bytes).
+  // An element's address = a UNIFORM row pointer (scalar registers) + ONE per-lane offset: written so that the 64
+  // accesses of a thread do not each hold a 64-bit address in vector registers (the first form did: 256 VGPRs + 160
+  // AGPRs, one workgroup per CU, and the first layer ran at 0.62-0.70 where the same-shape hidden layer reaches 0.85).
   auto acc_io = [&](const float* src, float* dst) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * WN + j * 32 + r;
+      const bool cok = col < p.N;
+      const unsigned loff = (unsigned)(4 * half) * (unsigned)p.N + (unsigned)col;      // < 2^31: 4 rows of N <= 2^28 floats
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-          if (row < p.rows && col < p.N) {
-            if (src) acc[i][j][e] = src[row * p.N + col];
-            else dst[row * p.N + col] = acc[i][j][e];
+          const int64_t urow = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2);   // uniform over the wave
+          const bool ok = cok && urow + 4 * half < p.rows;
+          if (src) {
+            const float* rp = src + urow * p.N;
+            if (ok) acc[i][j][e] = rp[loff];
+          } else {
+            float* wp = dst + urow * p.N;
+            if (ok) wp[loff] = acc[i][j][e];
           }
         }
     }
