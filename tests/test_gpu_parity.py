@@ -915,13 +915,15 @@ def test_selected_only_step_equals_both_directions_step(la, arch, fused, B):
     assert 0.2 < float((res[True][0][1] > 0).float().mean()) <= 1.0
 
 
-def test_mcmc_step_is_hip_graph_capturable(la):
+@pytest.mark.parametrize("B", [64, 2048, 6200])
+def test_mcmc_step_is_hip_graph_capturable(la, B):
     """include/l2hmc_hip.h promises no allocation / synchronisation inside the library: a whole MCMC step
-    (draws + trajectories + mix/accept + observables + wrap) is captured into a HIP graph and replayed."""
+    (draws + trajectories + mix/accept + observables + wrap) is captured into a HIP graph and replayed -- as one
+    sub-tile launch (64 chains), one 16-row launch (2048) and the three launches of a cut batch (6200: 32-row rounds,
+    a 16-row round, a sub-tile launch; launch_fused_step)."""
     import ctypes as C
     from l2hmc_amd import _lib
     T = X = 8
-    B = 64
     xp, vp = H.gauge_weights(T, X, regime="mild")
     orc = H.gauge_oracle(T, X, 3, 0.1, xp, vp)
     dyn = H.gauge_hip(T, X, 3, 0.1, xp, vp, orc.mask, B)
