@@ -1361,6 +1361,8 @@ def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
     rng = np.random.default_rng(21)
     x = torch.as_tensor(rng.uniform(0, 2 * np.pi, (B, 128)), dtype=torch.float32, device="cuda")
     v = torch.as_tensor(rng.standard_normal((B, 128)), dtype=torch.float32, device="cuda")
+    coin = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
+    uu = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
     L = _lib.lib()
     outs = {}
     try:
@@ -1374,11 +1376,13 @@ def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
             f = dyn.transition_kernel(x, beta, forward=True, momentum=v, return_logdet=True)
             b = dyn.transition_kernel(x, beta, forward=False, momentum=v, return_logdet=True)
             lf = dyn._forward_lf(x, v, beta, 2) + dyn._backward_lf(x, v, beta, 1)
+            # injected draws: both directions of the batch in one trajectory launch (rows = 2 B, x_mod / dir_split)
+            inj = dyn.apply_transition(x, beta, momentum_f=v, momentum_b=v.flip(0), coin=coin, u=uu)
             dyn.both_directions = False
             dyn._draws = 40
             sel = GaugeSampler(dyn).step(x, beta)[:2]
             dyn.both_directions = True
-            outs[sub] = [xn, px, obs["action"], obs["avg_plaq"], obs["top_charge"], dq, *tr, *f, *b, *lf, *sel,
+            outs[sub] = [xn, px, obs["action"], obs["avg_plaq"], obs["top_charge"], dq, *tr, *f, *b, *lf, *sel, *inj,
                          smp.stats.mean_accept()]
     finally:
         L.l2hmc_debug_fused_subtile(1)
