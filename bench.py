@@ -97,6 +97,21 @@ def config_macs(cfg):
     return conv_front_macs(L, F) + net_macs(D, H, nflat, nflat), dict(D=D, H=H, Ka=nflat, Kb=nflat, F=F)
 
 
+def executed_macs_per_lf(cfg, fused, active_cols):
+    """MACs per chain-LF step the kernels actually execute (the `frac` figures price the reference's count, 4 x
+    config_macs: it forms every first layer anew and every head column whatever the keep mask).
+    Kept first-layer products (both paths): of the 4 first layers / conv front-ends of a step 2.5 are formed (+ the
+    first momentum update of a trajectory).  active_cols (layer-by-layer path, rows' directions known per tile):
+    the two position sub-updates form S / T / Q for the half of the columns they move."""
+    c = CONFIGS[cfg]
+    _, d = config_macs(cfg)
+    D, H, N = d["D"], d["H"], c["N"]
+    l1 = (d["Ka"] + d["Kb"]) * H + (conv_front_macs(c["L"], d["F"]) if c["arch"] == "conv3D" else 0)
+    l1_calls = (2.5 * N + 1) / N
+    heads_calls = 3.0 if active_cols else 4.0
+    return l1_calls * l1 + 4 * (2 * H + H * H) + heads_calls * 3 * H * D
+
+
 def rank_chains(cfg, world, rank, scaling):
     """Chains [lo, hi) of the job's global batch that `rank` integrates, and the global batch.
     weak: per-GPU batch fixed, global = world x per_gpu.  strong: the config's global batch cut into `world`
@@ -215,7 +230,7 @@ def profile_class(Lh, cls, run, _lib):
     return (1e3 * ms.value / n.value if n.value else 0.0), int(n.value)
 
 
-def gauge_kernel_classes(cfg, rows, fused):
+def gauge_kernel_classes(cfg, rows, fused, active_cols=False):
     """(class id, kernel name, algorithmic FLOPs per launch) of the kernels a lattice step launches."""
     c = CONFIGS[cfg]
     macs, d = config_macs(cfg)
@@ -233,7 +248,9 @@ def gauge_kernel_classes(cfg, rows, fused):
     out = [(1, "gemm_relu_kernel<.,1> (first dense layer; average over whole and half-K launches)",
             kept * 2.0 * rows * H * (d["Ka"] + d["Kb"])),
            (2, "gemm_relu_kernel<.,2> (hidden dense layer)", 2.0 * rows * H * H),
-           (3, "heads_kernel (S/T/Q + sub-update + log-det)", 2.0 * rows * 3 * D * H)]
+           (3, "heads_kernel (S/T/Q + sub-update + log-det; average over momentum updates -- all columns -- and "
+               "position sub-updates -- the columns their keep mask lets move, where the rows' directions are known "
+               "per row tile)", (0.75 if active_cols else 1.0) * 2.0 * rows * 3 * D * H)]
     if c["arch"] == "conv3D":
         out.append((6, "conv3d_front_kernel (both inputs: conv1+relu+pool, conv2+relu+pool; VALU, priced at the "
                        "fp32 MFMA rate; average over two-input and one-input launches)",
@@ -358,7 +375,13 @@ def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roo
             from l2hmc_amd import _lib as _l
             plan = state["dyn"]._plan()
             fused = (not layered) and _l.lib().l2hmc_gauge_plan_fused(C.byref(plan)) == 1
-            classes = gauge_kernel_classes(cfg, rows, fused)
+            # (csrc/stq_dense.hip: launch_heads needs the forward / backward split on a row-tile edge)
+            active_cols = (not fused) and both and B % 128 == 0
+            classes = gauge_kernel_classes(cfg, rows, fused, active_cols)
+            ex = 2.0 * executed_macs_per_lf(cfg, fused, active_cols)
+            res["executed_flops_per_chain_lf"] = ex
+            res["whole_step_executed_tflops"] = ndir * glob * c["N"] * ex / (dt / steps) / 1e12 / job.world
+            res["whole_step_executed_frac"] = res["whole_step_executed_tflops"] / PEAK_F32_MFMA_TFLOPS
         nprof = max(1, min(steps, 20))
         per = []
         for cls, name, flops in classes:
@@ -379,6 +402,9 @@ def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roo
                                "avg_launch_us": dom["avg_us"], "algorithmic_flops_per_launch": dom["flops_per_launch"],
                                "all_kernels": per, "whole_step_tflops": res["whole_step_tflops"],
                                "whole_step_frac": res["whole_step_frac"]}
+            if "whole_step_executed_frac" in res:
+                res["roofline"]["whole_step_executed_tflops"] = res["whole_step_executed_tflops"]
+                res["roofline"]["whole_step_executed_frac"] = res["whole_step_executed_frac"]
     return res, state
 
 
@@ -724,6 +750,7 @@ def main():
         table = [{"cfg": 3, "workload": c["name"], "chains": st["B"], "ms_per_step": out["ms_per_step"],
                   "value": out["value"], "tflops": out.get("roofline", {}).get("whole_step_tflops"),
                   "frac": out.get("roofline", {}).get("whole_step_frac"),
+                  "executed_frac": out.get("roofline", {}).get("whole_step_executed_frac"),
                   "kernel": out.get("roofline", {}).get("kernel"),
                   "kernel_avg_us": out.get("roofline", {}).get("avg_launch_us"),
                   "kernel_frac": out.get("roofline", {}).get("frac")}]
@@ -735,6 +762,7 @@ def main():
                 rf = r.get("roofline", {})
                 table.append({"cfg": oc, "workload": r["workload"], "chains": s2["B"], "ms_per_step": r["ms_per_step"],
                               "value": r["value"], "tflops": r["whole_step_tflops"], "frac": r["whole_step_frac"],
+                              "executed_frac": r.get("whole_step_executed_frac"),
                               "kernel": rf.get("kernel"), "kernel_avg_us": rf.get("avg_launch_us"),
                               "kernel_frac": rf.get("frac"),
                               "kernels": [{"kernel": q["kernel"].split(" ")[0], "avg_us": q["avg_us"], "frac": q["frac"],
@@ -750,8 +778,10 @@ def main():
         out["configs"] = table
         out["configs_note"] = ("every BASELINE.json config on ONE GPU at its per-GPU size (configs 4 and 5: the 1/8 "
                                "shard of the 8-GPU partition, 1024 and 2048 chains); value = useful chain-LF/s, "
-                               "tflops / frac = executed algorithmic FLOPs of the whole step against the fp32 MFMA "
-                               "peak; `python bench.py --config c [--gpus N]` runs one of them as the headline")
+                               "tflops / frac = the reference's FLOPs of the whole step (every first layer and every "
+                               "head column formed anew) per second against the fp32 MFMA peak, executed_frac = the "
+                               "FLOPs the kernels actually execute (kept first-layer products, position sub-updates on "
+                               "the columns they move); `python bench.py --config c [--gpus N]` runs one of them as the headline")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

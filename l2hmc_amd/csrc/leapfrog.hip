@@ -2,6 +2,7 @@
 // mixing / Metropolis-Hastings, and the host-side orchestration of the lattice
 // trajectory: l2hmc/dynamics/gauge_dynamics.py:195-313, :412-609.
 #include "stq_dense.h"
+#include <atomic>
 #include <math.h>
 
 namespace l2hmc {
@@ -184,6 +185,7 @@ struct GaugeWs {
   float* h1; float* h2; float* g; float* ld_part; float* mask_inv; float* fa; float* fb;
   float* act0; float* kin0; float* act1; float* kin1;
   float* pre_v; float* pre_x;      // kept first-layer products [rows][H] (NULL when the plan recomputes them)
+  int* act_cols; int* act_cnt;     // [num_steps][2][D] / [num_steps][2]: columns a position sub-update moves (stq_dense.h)
   size_t bytes;
 };
 
@@ -230,6 +232,8 @@ static GaugeWs carve_gauge_ws(const l2hmc_gauge_plan* p, int64_t rows, void* ws)
                     dense_net_tileable(&p->vnet);
   w.pre_v = keep ? take((size_t)rows * p->vnet.H) : nullptr;
   w.pre_x = keep ? take((size_t)rows * p->xnet.H) : nullptr;
+  w.act_cols = reinterpret_cast<int*>(take((size_t)p->num_steps * 2 * D));
+  w.act_cnt = reinterpret_cast<int*>(take((size_t)p->num_steps * 2));
   w.bytes = off;
   return w;
 }
@@ -266,12 +270,21 @@ static int check_plan(const l2hmc_gauge_plan* p) {
   return L2HMC_OK;
 }
 
+// test / A-B hook (include/ does not declare it): 0 = every heads launch forms all columns
+static std::atomic<int> g_heads_active_cols{1};
+extern "C" int l2hmc_debug_heads_active_cols(int on) {
+  g_heads_active_cols.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+
 // one S/T/Q evaluation of `net` on (a, b*mask), fused with the v or x update
 static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, const float* a,
                       const float* b, const float* cm_f, const float* cm_b, const int* dir,
                       const float tcs[4], int64_t rows, int mode, float* x, float* v, const float* g,
                       const float* keep_f, const float* keep_b, float eps, const GaugeWs& w, int ncb,
-                      hipStream_t stream, int carry = kCarryNone) {
+                      hipStream_t stream, int carry = kCarryNone, const int* cols_f = nullptr,
+                      const int* cols_b = nullptr, const int* cnt_f = nullptr, const int* cnt_b = nullptr,
+                      int64_t dir_split = -1) {
   if (carry == kCarryVUse) {
     // same (x, force) as the call that kept the product: only bias + time term + relu remain of the first layer
     L1FinishArgs f{};
@@ -321,6 +334,10 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
   h.q_tanh = net->q_tanh; h.D = net->D; h.rows = rows; h.mode = mode;
   h.x = x; h.v = v; h.g = g; h.dir = dir; h.keep_f = keep_f; h.keep_b = keep_b; h.eps = eps;
   h.ld_part = w.ld_part; h.ncb = ncb;
+  if (mode == 2 && dir_split >= 0 && g_heads_active_cols.load(std::memory_order_relaxed)) {
+    // only the columns this sub-update moves (the others' S, T, Q are multiplied by 1 - keep = 0)
+    h.cols_f = cols_f; h.cols_b = cols_b; h.cnt_f = cnt_f; h.cnt_b = cnt_b; h.dir_split = dir_split;
+  }
   return launch_heads(h, stream);
 }
 
@@ -338,7 +355,7 @@ static bool carry_possible(const l2hmc_gauge_plan* p, const float* x, const floa
 // keep_last: keep them for the next step
 static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float* x, float* v,
                          const int* dir, int64_t rows, const GaugeWs& w, hipStream_t stream, bool carry = false,
-                         bool use_prev = false, bool keep_last = false) {
+                         bool use_prev = false, bool keep_last = false, int64_t dir_split = -1) {
   const int D = 2 * p->T * p->X;
   const int N = p->num_steps;
   const int sf = step, sb = N - 1 - step;   // gauge_dynamics.py:453-457
@@ -368,8 +385,13 @@ static int leapfrog_step(const l2hmc_gauge_plan* p, float beta, int step, float*
                              nullptr, nullptr, p->eps, dir, 0, rows, D, x, nullptr, 0);
           L2HMC_CHECK_LAUNCH("lf_update_x");
         } else {
+          // active columns: keep = mask -> list 0 of that mask row, keep = 1 - mask -> list 1 (active_cols_kernel)
+          const int wf = sub == 0 ? 0 : 1, wb = sub == 0 ? 1 : 0;
+          const int* lf = w.act_cols + ((size_t)sf * 2 + wf) * D;
+          const int* lb = w.act_cols + ((size_t)sb * 2 + wb) * D;
           if (int e = net_update(p, &p->xnet, v, x, kf, kb, dir, tcs, rows, /*mode x*/ 2, x, v, nullptr, kf, kb,
-                                 p->eps, w, ncb, stream, !carry ? kCarryNone : sub == 0 ? kCarryXFirst : kCarrySecond))
+                                 p->eps, w, ncb, stream, !carry ? kCarryNone : sub == 0 ? kCarryXFirst : kCarrySecond,
+                                 lf, lb, w.act_cnt + sf * 2 + wf, w.act_cnt + sb * 2 + wb, dir_split))
             return e;
         }
       }
@@ -399,6 +421,7 @@ static int prepare_ws(const l2hmc_gauge_plan* p, int64_t rows, const GaugeWs& w,
   hipLaunchKernelGGL(invert_mask_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, p->masks,
                      w.mask_inv, n);
   L2HMC_CHECK_LAUNCH("invert_mask");
+  if (int e = launch_active_cols(p->masks, p->num_steps, D, w.act_cols, w.act_cnt, stream)) return e;
   if (hipMemsetAsync(w.ld_part, 0, sizeof(float) * (size_t)rows * gauge_ncb(p), stream) != hipSuccess) {
     set_error("hipMemsetAsync(ld_part) failed");
     return L2HMC_ERR_HIP;
@@ -407,9 +430,11 @@ static int prepare_ws(const l2hmc_gauge_plan* p, int64_t rows, const GaugeWs& w,
 }
 
 // x, v: [rows][D] integrated in place over all num_steps; optional sumlogdet / p
+// dir_split: rows [0, dir_split) are known to run forward and [dir_split, rows) backward (-1: directions are whatever
+// `dir` says per row; then every heads launch forms all columns)
 static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, float* v, const int* dir,
                               int64_t rows, float* sumlogdet, float* p_accept, const GaugeWs& w,
-                              hipStream_t stream) {
+                              hipStream_t stream, int64_t dir_split = -1) {
   const int D = 2 * p->T * p->X;
   if (use_fused(p))
     return launch_fused_trajectory(p, beta, 0, p->num_steps, x, v, dir, rows, x, v, sumlogdet, 0, p_accept,
@@ -426,7 +451,7 @@ static int trajectory_inplace(const l2hmc_gauge_plan* p, float beta, float* x, f
   //  9.75 -> 10.18 ms, cfg 3 layered 2.58 -> 2.63 ms)
   for (int step = 0; step < p->num_steps; ++step)
     if (int e = leapfrog_step(p, beta, step, x, v, dir, rows, w, stream, carry, carry && step > 0,
-                              carry && step + 1 < p->num_steps))
+                              carry && step + 1 < p->num_steps, dir ? dir_split : rows))
       return e;
   if (p_accept) {
     if (int e = launch_u1_action_force(x, rows, p->T, p->X, beta, w.act1, nullptr, nullptr, nullptr, stream))
@@ -617,7 +642,9 @@ extern "C" int l2hmc_gauge_leapfrog(const l2hmc_gauge_plan* plan, float beta, in
   if (use_fused(plan))
     return launch_fused_trajectory(plan, beta, step, step + 1, x, v, dir, rows, x, v, logdet, 1, nullptr, s);
   if (int e = prepare_ws(plan, rows, w, s)) return e;
-  if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s, carry_possible(plan, x, v, w))) return e;
+  if (int e = leapfrog_step(plan, beta, step, x, v, dir, rows, w, s, carry_possible(plan, x, v, w), false, false,
+                            dir ? -1 : rows))
+    return e;
   if (logdet) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, s, w.ld_part,
                        gauge_ncb(plan), rows, logdet, 1);
@@ -696,7 +723,7 @@ extern "C" int l2hmc_gauge_transition(const l2hmc_gauge_plan* plan, float beta, 
     if (int e = copy_async(Vw + (size_t)B * D, v0_b, nb, s)) return e;
     hipLaunchKernelGGL(fill_dir_kernel, dim3((unsigned)ceil_div(2 * B, 256)), dim3(256), 0, s, dirw, B);
     L2HMC_CHECK_LAUNCH("fill_dir");
-    if (int e = trajectory_inplace(plan, beta, Xw, Vw, dirw, R, nullptr, Pw, w, s)) return e;
+    if (int e = trajectory_inplace(plan, beta, Xw, Vw, dirw, R, nullptr, Pw, w, s, /*dir_split*/ B)) return e;
     hipLaunchKernelGGL(mix_accept_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, x, Xw, Vw, Pw,
                        Xw + (size_t)B * D, Vw + (size_t)B * D, Pw + B, coin, u, 1, B, D, x_prop, v_prop,
                        p_accept, x_out);

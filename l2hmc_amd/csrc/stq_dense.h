@@ -56,6 +56,11 @@ struct HeadsArgs {
   float* ld_part; int ncb;               // [rows][ncb] log-det partials, += own slot
   int mtiles, ntiles;
   unsigned long long* stamps;            // diagnostic builds only
+  // Position sub-updates only touch the columns their keep mask does not hold fixed (x' = keep x + (1 - keep) (...),
+  // the log-det term carries the same factor): with these set the kernels form S / T / Q for those columns alone.
+  // cols_f / cols_b: ascending column lists for forward / backward rows, *cnt_f / *cnt_b their lengths (device
+  // memory, written by active_cols_kernel); rows >= dir_split are the backward ones (a multiple of the row tile).
+  const int* cols_f; const int* cols_b; const int* cnt_f; const int* cnt_b; int64_t dir_split;
 };
 
 // In-kernel cycle stamps (cdna_hip_programming.md section 7): compiled in only with
@@ -122,6 +127,8 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream);
 
 int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream);
 int launch_heads(HeadsArgs& a, hipStream_t stream);
+// lists[s][0] = columns with mask[s][c] != 1, lists[s][1] = columns with mask[s][c] != 0 (ascending), counts[s][0..1]
+int launch_active_cols(const float* masks, int num_steps, int D, int* lists, int* counts, hipStream_t stream);
 int dense_net_supported(const l2hmc_dense_net* n);
 int dense_net_tileable(const l2hmc_dense_net* n);   // every width a multiple of 32 (fast staged loads)
 int fused_plan_supported(const l2hmc_gauge_plan* p);

@@ -399,10 +399,18 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   const int q = lane >> 4, r = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
+  // Active-column form (HeadsArgs::cols_f): the tiles are walked column block by column block in launch order, so the
+  // column blocks past the end of the list -- which leave at once -- come last and the live workgroups spread over
+  // all CUs (row-major order interleaves live and empty tiles: the live ones doubled up on half the CUs).
+  const int tile = p.cols_f ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_id = p.cols_f ? tile % p.mtiles : tile / p.ntiles;
+  const int nt_id = p.cols_f ? tile / p.mtiles : tile - mt_id * p.ntiles;
   const int64_t m0 = (int64_t)mt_id * BM;
   const int n0 = nt_id * BNH;
+  // output column n of this tile is column cols[n] of the heads
+  const int* cols = p.cols_f ? (m0 >= p.dir_split ? p.cols_b : p.cols_f) : nullptr;
+  const int ncol = cols ? *(m0 >= p.dir_split ? p.cnt_b : p.cnt_f) : p.D;
+  if (n0 >= ncol) return;                  // (uniform; before any barrier)
 
   int a_row[A_CH], a_kc[A_CH];
   bool a_ok[A_CH];
@@ -422,8 +430,9 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     b_row[i] = c / CPR;                     // 0..95 = head * 32 + nn
     b_kc[i] = (c % CPR) * 4;
     const int hd = b_row[i] >> 5, nn = b_row[i] & 31;
-    b_ok[i] = (n0 + nn) < p.D;
-    b_src[i] = ((int64_t)hd * p.D + n0 + nn) * p.K;
+    b_ok[i] = (n0 + nn) < ncol;
+    const int wcol = cols ? cols[b_ok[i] ? n0 + nn : ncol - 1] : n0 + nn;
+    b_src[i] = ((int64_t)hd * p.D + wcol) * p.K;
   }
 
   f32x4 ra[A_CH], rb[B_CH];
@@ -509,9 +518,10 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 
   L2HMC_STAMP(2);
   // --- epilogue.  C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
-  // acc[h][i]: rows m0 + 32 wm + 16 i + 4 q + e, column n0 + 16 wn + r
-  const int col = n0 + wn * 16 + r;
-  const bool cok = col < p.D;
+  // acc[h][i]: rows m0 + 32 wm + 16 i + 4 q + e, column n0 + 16 wn + r (of the active list, if there is one)
+  const int cidx = n0 + wn * 16 + r;
+  const bool cok = cidx < ncol;
+  const int col = cols ? cols[cok ? cidx : ncol - 1] : cidx;
   const HeadsCol c = heads_col(p, col, cok);
   float ld[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -576,10 +586,18 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r = lane & 31;
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
+  // Active-column form (HeadsArgs::cols_f): the tiles are walked column block by column block in launch order, so the
+  // column blocks past the end of the list -- which leave at once -- come last and the live workgroups spread over
+  // all CUs (row-major order interleaves live and empty tiles: the live ones doubled up on half the CUs).
+  const int tile = p.cols_f ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_id = p.cols_f ? tile % p.mtiles : tile / p.ntiles;
+  const int nt_id = p.cols_f ? tile / p.mtiles : tile - mt_id * p.ntiles;
   const int64_t m0 = (int64_t)mt_id * BM;
   const int n0 = nt_id * BNH;
+  // output column n of this tile is column cols[n] of the heads
+  const int* cols = p.cols_f ? (m0 >= p.dir_split ? p.cols_b : p.cols_f) : nullptr;
+  const int ncol = cols ? *(m0 >= p.dir_split ? p.cnt_b : p.cnt_f) : p.D;
+  if (n0 >= ncol) return;                  // (uniform; before any barrier)
 
   // unconditional, clamped tile loads (rows past the end repeat the last row: their products are never stored)
   const float* a_src[A_CH];
@@ -599,7 +617,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
     const int c = tid + i * kGemmThreads;
     const int row = c / CPR, kc = (c % CPR) * 4;     // row = head * 64 + nn
     const int hd = row >> 6, nn = row & 63;
-    const int col = (n0 + nn) < p.D ? n0 + nn : p.D - 1;
+    const int cidx = (n0 + nn) < ncol ? n0 + nn : ncol - 1;
+    const int col = cols ? cols[cidx] : cidx;
     b_src[i] = p.Wt + ((int64_t)hd * p.D + col) * p.K + kc;
     b_off[i] = (BM + row) * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
@@ -658,8 +677,9 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   }
 
   // --- epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  const int col = n0 + wn * 32 + r;
-  const bool cok = col < p.D;
+  const int cidx = n0 + wn * 32 + r;
+  const bool cok = cidx < ncol;
+  const int col = cols ? cols[cok ? cidx : ncol - 1] : cidx;
   const HeadsCol c = heads_col(p, col, cok);
   const int slot = (n0 >> 5) + wn;                   // this wave's 32-column log-det slot (ncb = ceil(D / 32))
 #pragma unroll
@@ -794,10 +814,52 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
   return L2HMC_OK;
 }
 
+// Ascending lists of the columns a position sub-update does not hold fixed: block (s, which) walks mask row s in
+// chunks of 256 columns and compacts those with keep != 1, where keep = mask (which 0) or 1 - mask (which 1).
+__global__ __launch_bounds__(256) void active_cols_kernel(const float* __restrict__ masks, int D, int* __restrict__ lists,
+                                                          int* __restrict__ counts) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int s = blockIdx.x >> 1, which = blockIdx.x & 1;
+  const float* m = masks + (size_t)s * D;
+  int* out = lists + ((size_t)s * 2 + which) * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    bool act = false;
+    if (c < D) {
+      const float keep = which == 0 ? m[c] : 1.f - m[c];     // (invert_mask_kernel forms 1 - mask the same way)
+      act = keep != 1.f;
+    }
+    const unsigned long long b = __ballot(act);
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (act) out[off + __popcll(b & ((1ull << lane) - 1ull))] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[s * 2 + which] = base;
+}
+
+int launch_active_cols(const float* masks, int num_steps, int D, int* lists, int* counts, hipStream_t stream) {
+  hipLaunchKernelGGL(active_cols_kernel, dim3((unsigned)(2 * num_steps)), dim3(256), 0, stream, masks, D, lists, counts);
+  L2HMC_CHECK_LAUNCH("active_cols");
+  return L2HMC_OK;
+}
+
 int launch_heads(HeadsArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.K > 0 && a.D > 0 && a.A && a.Wt, "heads: bad arguments");
   const bool ragged = a.K % BK != 0 || a.lda % 4 != 0 || !aligned16(a.A) || !aligned16(a.Wt);
+  // the active-column form needs row tiles of ONE direction: the split between forward and backward rows on a tile edge
+  auto split_ok = [&](int bm) { return a.dir_split >= a.rows || a.dir_split % bm == 0; };
+  if (a.cols_f && (a.mode != kHeadsUpdateX || !a.cols_b || !a.cnt_f || !a.cnt_b)) a.cols_f = nullptr;
   if (ragged) {
+    a.cols_f = nullptr;
     a.mtiles = (int)ceil_div(a.rows, 64);
     a.ntiles = (int)ceil_div(a.D, 32);
     L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
@@ -813,6 +875,7 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
       (a.ld_part == nullptr || a.ncb == a.D / 32)) {
     a.mtiles = (int)ceil_div(a.rows, 128);
     a.ntiles = a.D / 64;
+    if (a.cols_f && !split_ok(128)) a.cols_f = nullptr;
     prof_before(kProfHeads, stream);
     hipLaunchKernelGGL(heads32_kernel, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
     prof_after(kProfHeads, stream);
@@ -822,6 +885,7 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
   a.mtiles = (int)ceil_div(a.rows, 64);
   a.ntiles = (int)ceil_div(a.D, 32);
   L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
+  if (a.cols_f && !split_ok(64)) a.cols_f = nullptr;
   prof_before(kProfHeads, stream);
   if (a.K % 64 == 0 && a.mtiles * a.ntiles <= 256)
     hipLaunchKernelGGL(heads_kernel<64>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);

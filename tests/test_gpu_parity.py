@@ -1343,6 +1343,47 @@ def test_kept_products_equal_recomputed(la, L, arch, N, B):
     assert H.relerr(np_(outs[False][0]), want[0]) < 2 * TOL_OP and H.relerr(np_(outs[False][1]), want[1]) < 2 * TOL_OP
 
 
+# ----------------------------------------------------------------- heads on the active columns only (layer-by-layer path)
+@pytest.mark.parametrize("L,arch,N,B", [(8, "generic", 4, 128), (8, "generic", 3, 192), (16, "conv3D", 3, 64),
+                                        (16, "generic", 2, 256), (8, "conv3D", 3, 64), (8, "generic", 3, 37)])
+def test_active_column_heads_equal_all_columns(la, L, arch, N, B):
+    """A position sub-update moves only the columns its keep mask does not hold fixed (gauge_dynamics.py:519-531,
+    :574-584: x' = keep x + (1 - keep) (...), the log-det term carries the same factor), so where the rows' directions
+    are known per row tile (apply_transition: rows [0, B) forward, [B, 2B) backward; forward-only trajectories) the
+    layer-by-layer path forms S / T / Q for those columns alone (csrc/stq_dense.hip: HeadsArgs::cols_f, lists from
+    active_cols_kernel).  A column's dot product keeps its k order, so x, v and the accept probability's inputs must
+    EQUAL the all-columns evaluation; the log-det is the same terms added tile by tile in another grouping (fp32
+    rounding).  B = 37 (rows not whole tiles: the split is not on a tile edge) takes the all-columns path either way."""
+    from l2hmc_amd import _lib
+    mk = H.conv_weights if arch == "conv3D" else H.gauge_weights
+    xp, vp = mk(L, L, regime="mild")
+    orc = H.gauge_oracle(L, L, N, 0.15, xp, vp, arch=arch)
+    dyn = H.gauge_hip(L, L, N, 0.15, xp, vp, orc.mask, B, arch=arch)
+    dyn.fused = False
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * L * L, seed=313)
+    Lh = _lib.lib()
+    outs = {}
+    try:
+        for on in (1, 0):
+            Lh.l2hmc_debug_heads_active_cols(on)
+            f = dyn.transition_kernel(x, 2.0, forward=True, momentum=v0f, return_logdet=True)
+            tr = dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+            lf = dyn._forward_lf(x, v0f, 2.0, 1)
+            outs[on] = (f, tr, lf)
+    finally:
+        Lh.l2hmc_debug_heads_active_cols(1)
+    (f1, tr1, lf1), (f0, tr0, lf0) = outs[1], outs[0]
+    assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])                  # x, v of the forward trajectory
+    assert torch.equal(lf1[0], lf0[0]) and torch.equal(lf1[1], lf0[1])              # one leapfrog step
+    assert torch.equal(tr1[0], tr0[0]) and torch.equal(tr1[1], tr0[1]) and torch.equal(tr1[3], tr0[3])
+    scale = max(1.0, float(f0[3].abs().max()))
+    assert float((f1[3] - f0[3]).abs().max()) <= 2e-6 * scale                      # sum of log-dets: grouping only
+    assert float((lf1[2] - lf0[2]).abs().max()) <= 2e-6 * max(1.0, float(lf0[2].abs().max()))
+    assert float((f1[2] - f0[2]).abs().max()) <= 1e-5 and float((tr1[2] - tr0[2]).abs().max()) <= 1e-5   # p_accept
+    want = orc.transition_kernel(x, 2.0, v0f, forward=True)
+    assert H.relerr(np_(f1[0]), want[0]) < 2 * TOL_OP and H.relerr(np_(f1[1]), want[1]) < 2 * TOL_OP
+
+
 # ----------------------------------------------------------------- sub-tile form of the whole-trajectory kernel
 @pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536, 2049, 2304, 3000, 3600, 4096, 4100, 5000, 6000, 6200])
 def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
