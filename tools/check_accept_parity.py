@@ -1,7 +1,9 @@
 """One-off evidence (not a test): accept-rate parity over >= 1000 MCMC steps (north_star: +-1 %).  At every step
 the float64 oracle sees the device chain's state and the same draws, as in
 tests/test_gpu_parity.py::test_accept_rate_parity_on_identical_inputs, but for 1000 steps and two regimes.
-    python tools/check_accept_parity.py [steps] [chains]"""
+    python tools/check_accept_parity.py [steps] [chains] [layered]
+`layered`: the layer-by-layer kernels instead of the whole-trajectory kernel (with 64 chains or a multiple, the position
+sub-updates then run on the columns they move: csrc/stq_dense.hip, HeadsArgs::cols_f)."""
 import os
 import sys
 import time
@@ -12,12 +14,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import helpers as H  # noqa: E402
 
 
-def run(tag, N, eps, regime, steps, B):
+def run(tag, N, eps, regime, steps, B, layered=False):
     T = X = 8
     xp, vp = H.gauge_weights(T, X, regime=regime)
     orc = H.gauge_oracle(T, X, N, eps, xp, vp)
     orc32 = H.gauge_oracle(T, X, N, eps, xp, vp, dtype=np.float32)     # the reference's own precision, same inputs
     dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+    dyn.fused = not layered
     rng = np.random.default_rng(11)
     x = rng.uniform(0, 2 * np.pi, (B, 128)).astype(np.float32)
     ph, po, ah, ao, pf = [], [], [], [], []
@@ -81,6 +84,9 @@ def run_mog(steps, B):
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    run("moderate acceptance", 5, 0.08, "init", steps, B)
-    run("benchmark dynamics", 10, 0.25, "init", steps, B)
-    run_mog(steps, 64)
+    layered = len(sys.argv) > 3 and sys.argv[3] == "layered"
+    tag = " (layer-by-layer kernels)" if layered else ""
+    run("moderate acceptance" + tag, 5, 0.08, "init", steps, B, layered)
+    run("benchmark dynamics" + tag, 10, 0.25, "init", steps, B, layered)
+    if not layered:
+        run_mog(steps, 64)
