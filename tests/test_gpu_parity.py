@@ -1384,6 +1384,46 @@ def test_active_column_heads_equal_all_columns(la, L, arch, N, B):
     assert H.relerr(np_(f1[0]), want[0]) < 2 * TOL_OP and H.relerr(np_(f1[1]), want[1]) < 2 * TOL_OP
 
 
+def test_active_column_heads_with_any_mask(la):
+    """The column lists are built from the masks as they are (csrc/stq_dense.hip: active_cols_kernel keeps a column
+    wherever keep != 1): rows with 30 % / 80 % ones, an all-ones and an all-zeros row (one of the two sub-updates then
+    has NO active column: every heads workgroup of that launch leaves at once) and fractional entries (the column stays
+    in both lists).  Against the float64 oracle with the same masks, and equal to the all-columns evaluation."""
+    from l2hmc_amd import _lib
+    from oracle.gauge_dynamics import GaugeDynamicsOracle
+    T = X = 8
+    D, N, B = 128, 5, 128
+    rng = np.random.default_rng(5)
+    masks = np.zeros((N, D))
+    masks[0, rng.permutation(D)[:38]] = 1.0
+    masks[1, rng.permutation(D)[:102]] = 1.0
+    masks[2, :] = 1.0
+    masks[3, :] = 0.0
+    masks[4, rng.permutation(D)[:64]] = 1.0
+    masks[4, rng.permutation(D)[:9]] = 0.5
+    masks[0, 7] = 0.25
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = GaugeDynamicsOracle(T, X, N, 0.1, masks, xp, vp, "generic")
+    dyn = H.gauge_hip(T, X, N, 0.1, xp, vp, masks, B)
+    dyn.fused = False
+    x, v0f, v0b, coin, u = H.gauge_inputs(B, D, seed=317)
+    Lh = _lib.lib()
+    outs = {}
+    try:
+        for on in (1, 0):
+            Lh.l2hmc_debug_heads_active_cols(on)
+            outs[on] = dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+    finally:
+        Lh.l2hmc_debug_heads_active_cols(1)
+    for a, b in ((outs[1][0], outs[0][0]), (outs[1][1], outs[0][1]), (outs[1][3], outs[0][3])):
+        assert torch.equal(a, b)
+    assert float((outs[1][2] - outs[0][2]).abs().max()) <= 1e-5
+    want = orc.apply_transition(x, 2.0, v0f, v0b, coin, u)
+    assert H.relerr(np_(outs[1][0]), want[0]) < 2 * TOL_OP and H.relerr(np_(outs[1][1]), want[1]) < 2 * TOL_OP
+    assert np.abs(np_(outs[1][2]) - want[2]).max() < TOL_P
+    assert H.relerr(np_(outs[1][3]), want[3]) < 2 * TOL_OP
+
+
 # ----------------------------------------------------------------- sub-tile form of the whole-trajectory kernel
 @pytest.mark.parametrize("B", [3, 130, 256, 500, 700, 1024, 1100, 1536, 2049, 2304, 3000, 3600, 4096, 4100, 5000, 6000, 6200])
 def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
