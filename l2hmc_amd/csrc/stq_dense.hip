@@ -382,9 +382,12 @@ __device__ __forceinline__ float heads_element(const HeadsArgs& p, const HeadsCo
   return (1.f - keep) * s;
 }
 
-template <int BK, bool RAGGED = false>
+// BM = 32: half-height row tiles for launches with few live tiles (the active-column form of a small batch: cfg 4's
+// position sub-updates have 256 live 64-row tiles, one per CU, and a lone workgroup keeps the matrix pipe half busy)
+template <int BK, bool RAGGED = false, int BM = 64>
 __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
-  constexpr int BM = 64, BNH = 32, NB = 3 * BNH;
+  constexpr int BNH = 32, NB = 3 * BNH;
+  constexpr int RG = BM / 32;             // 16-row groups per wave (wave grid 2 x 2: BM / 2 rows x 16 columns per wave)
   constexpr int CPR = BK / 4;
   constexpr int LDK = BK + 8;             // 40 / 72 floats (= 8 mod 64): conflict-free for the 16-row fragment reads
   constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
@@ -478,11 +481,11 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
       *reinterpret_cast<f32x4*>(bb + b_row[i] * LDK + b_kc[i]) = rb[i];
   };
 
-  f32x4 acc[3][2];
+  f32x4 acc[3][RG];
 #pragma unroll
   for (int h = 0; h < 3; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RG; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
   load_tile(0);
@@ -495,13 +498,13 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     // wave (wm, wn): rows [32 wm, 32 wm + 32) x columns [16 wn, 16 wn + 16) of all three heads -- per 16 k two row
     // fragments and three column fragments feed 24 MFMAs (5 ds_read_b128; a wave owning 16 rows x all 96 columns
     // read 7)
-    const float* as = lds + cur * STAGE + (wm * 32 + r) * LDK + q * 4;
+    const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + q * 4;
     const float* bs = lds + cur * STAGE + BM * LDK + (wn * 16 + r) * LDK + q * 4;
 #pragma unroll
     for (int kh = 0; kh < BK / 16; ++kh) {
-      f32x4 af[2], bf[3];
+      f32x4 af[RG], bf[3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + kh * 16);
+      for (int i = 0; i < RG; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + kh * 16);
 #pragma unroll
       for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + kh * 16);
 #pragma unroll
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < RG; ++i)
             acc[h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[h][e], acc[h][i], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
@@ -523,38 +526,42 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   const bool cok = cidx < ncol;
   const int col = cols ? cols[cok ? cidx : ncol - 1] : cidx;
   const HeadsCol c = heads_col(p, col, cok);
-  float ld[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float ld[RG][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RG; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ld[i][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < RG; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t row = m0 + wm * 32 + i * 16 + q * 4 + e;
+      const int64_t row = m0 + wm * (BM / 2) + i * 16 + q * 4 + e;
       if (row >= p.rows || !cok) continue;
       ld[i][e] = heads_element(p, c, row, col, acc[0][i][e], acc[1][i][e], acc[2][i][e]);
     }
   if (p.mode != kHeadsMaterialise && p.ld_part) {
     // a row's 32 columns of this workgroup sit in two waves (wn = 0, 1): each reduces its 16 lanes, the second hands
     // its sums over through LDS (the stage buffers are free), the first adds them in a fixed order
-    float t[2][4];
+    float t[RG][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RG; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[i][e] = row16_sum(ld[i][e]);   // DPP on the VALU
-    float* hand = lds;                                    // [wm][32 rows]
+    float* hand = lds;                                    // [wm][BM / 2 rows]
     if (wn == 1 && r == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RG; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hand[wm * 32 + i * 16 + q * 4 + e] = t[i][e];
+        for (int e = 0; e < 4; ++e) hand[wm * (BM / 2) + i * 16 + q * 4 + e] = t[i][e];
     }
     __syncthreads();
     if (wn == 0 && r == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RG; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int64_t row = m0 + wm * 32 + i * 16 + q * 4 + e;
-          if (row < p.rows) p.ld_part[row * p.ncb + nt_id] += t[i][e] + hand[wm * 32 + i * 16 + q * 4 + e];
+          const int64_t row = m0 + wm * (BM / 2) + i * 16 + q * 4 + e;
+          if (row < p.rows) p.ld_part[row * p.ncb + nt_id] += t[i][e] + hand[wm * (BM / 2) + i * 16 + q * 4 + e];
         }
     }
   }
@@ -887,6 +894,16 @@ int launch_heads(HeadsArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.ld_part == nullptr || a.ncb == a.ntiles, "heads: ncb=%d != %d", a.ncb, a.ntiles);
   if (a.cols_f && !split_ok(64)) a.cols_f = nullptr;
   prof_before(kProfHeads, stream);
+  // active-column launches keep about half of their column blocks: with fewer than two live 64-row tiles per CU, 32-row
+  // tiles put two workgroups on every CU again
+  // (32-row tiles for the all-columns launches as well -- 1024 workgroups, three per CU -- were measured: 69 -> 72 us)
+  if (a.cols_f && (int64_t)a.mtiles * a.ntiles / 2 < 512 && split_ok(32) && a.rows % 32 == 0) {
+    a.mtiles = (int)ceil_div(a.rows, 32);
+    hipLaunchKernelGGL((heads_kernel<32, false, 32>), dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
+    prof_after(kProfHeads, stream);
+    L2HMC_CHECK_LAUNCH("heads (32-row tiles)");
+    return L2HMC_OK;
+  }
   if (a.K % 64 == 0 && a.mtiles * a.ntiles <= 256)
     hipLaunchKernelGGL(heads_kernel<64>, dim3(a.mtiles * a.ntiles), dim3(kGemmThreads), 0, stream, a);
   else
