@@ -261,6 +261,11 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   L2HMC_STAMP(2);
   // --- epilogue: + bias (+ t.Wt), relu, store.  C layout of 32x32 MFMA:
   // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // Aligned shapes: the tile goes through LDS (the stage buffers are free) and leaves as 16-byte pieces of whole rows
+  // -- a wave's store instruction covers 2 x 512 contiguous bytes instead of 2 x 128.
+  constexpr int LDC = BN + 4;                           // row stride of the staged tile (floats)
+  static_assert(RAGGED || BM * LDC <= 2 * STAGE, "the output tile must fit the stage buffers");
+  const bool staged = !RAGGED && (p.ldo % 4) == 0 && (p.N % 4) == 0 && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * WN + j * 32 + r;
@@ -272,7 +277,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int lrow = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int64_t row = m0 + lrow;
         if (row < p.rows && cok) {
           float h;
           if (KIND == 1) {
@@ -282,9 +288,22 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
             h = acc[i][j][e] + bj;
           }
           if (KIND == 3) h = p.gate[row * p.ldg + col] > 0.f ? h : 0.f;
-          p.out[row * p.ldo + col] = KIND <= 2 ? fmaxf(h, 0.f) : h;
+          h = KIND <= 2 ? fmaxf(h, 0.f) : h;
+          if (staged) lds[lrow * LDC + wn * WN + j * 32 + r] = h;
+          else p.out[row * p.ldo + col] = h;
         }
       }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    constexpr int C4 = BN / 4;                          // 16-byte pieces per tile row
+#pragma unroll 4
+    for (int c = tid; c < BM * C4; c += kGemmThreads) {
+      const int lrow = c / C4, c4 = (c - lrow * C4) * 4;
+      const int64_t row = m0 + lrow;
+      if (row < p.rows && n0 + c4 < p.N)                // (N is a multiple of 4: a piece is inside or outside)
+        *reinterpret_cast<f32x4*>(p.out + row * p.ldo + n0 + c4) = *reinterpret_cast<const f32x4*>(lds + lrow * LDC + c4);
     }
   }
   L2HMC_STAMP(3);
