@@ -191,6 +191,11 @@ int l2hmc_mix_accept(const float* x, const float* xf, const float* vf, const flo
                                       * does, instead of keeping the ones a leapfrog step repeats (XNet's product with
                                       * the momentum across the two position sub-updates; VNet's whole product from the
                                       * end of one step to the start of the next).  Same bits either way; diagnostic */
+#define L2HMC_PLAN_TILES16_ONLY 16   /* whole-trajectory kernel: every batch on the 16-row form (no sub-tile form, no 32-row
+                                      * form, no launch split).  All forms give the same bits; A/B and the bit-identity test */
+#define L2HMC_PLAN_ALL_COLUMNS 32    /* layer-by-layer path: a position sub-update forms S / T / Q for EVERY column, as the
+                                      * reference's graph does, instead of only the columns its mask lets move (identical x, v
+                                      * for finite trajectories; 0 x non-finite differs: DESIGN.md D1) */
 typedef struct l2hmc_gauge_plan {
   int32_t T, X;            /* lattice extents; D = 2*T*X */
   int32_t num_steps;       /* N_LF */
@@ -210,6 +215,11 @@ size_t l2hmc_gauge_ws_bytes(const l2hmc_gauge_plan* plan, int64_t rows);
  * 1 = a whole-trajectory kernel exists for this shape and L2HMC_PLAN_LAYERED is not set, 0 = layer by layer,
  * negative = invalid plan (l2hmc_last_error says why). */
 int l2hmc_gauge_plan_fused(const l2hmc_gauge_plan* plan);
+
+/* How one MCMC step of a whole-trajectory plan (GenericNet, 8x8) over `rows_all` chain-rows is cut into launches on a
+ * device with `cus` compute units (host logic only, no device call, no reference counterpart): writes up to three
+ * {rows, rows per workgroup} parts and returns their number.  Rows per workgroup 4 / 8 / 12 = sub-tile form, 16, 32. */
+int l2hmc_gauge_step_plan(int64_t rows_all, int32_t cus, int64_t* rows_out, int32_t* rows_per_wg_out);
 
 /* One augmented leapfrog step IN PLACE on x, v: [rows][D]; dir: [rows] int32 per
  * row (0 fwd, 1 bwd), or NULL = all forward.  `step` is the loop counter t of
@@ -386,7 +396,8 @@ typedef struct l2hmc_mog_target {
 typedef struct l2hmc_small_plan {
   int32_t x_dim, num_nodes, trajectory_length, hmc;
   float eps;
-  float reserved;
+  int32_t first_layer_form;        /* 0: chosen by batch size; 1 / 2: force the matrix-pipe / VALU form of the first layer
+                                    * (they walk the hidden layer's k in different orders and agree to rounding) */
   const float* masks;              /* [trajectory_length][x_dim] */
   l2hmc_dense_net xnet, vnet;      /* q_tanh = 1, Ka = Kb = x_dim */
   l2hmc_mog_target target;
@@ -408,12 +419,6 @@ int l2hmc_small_trajectory(const l2hmc_small_plan* plan, const float* x0, const 
  * fill x 4 + l2hmc_small_trajectory(2B rows) + l2hmc_mix_accept(strict = 0) bit for bit.  Both trajectories of a
  * chain run in the same wave.  Outputs (each may be NULL): Lx, Lv [B][x_dim] the proposal selected by the direction
  * bit (forward iff uniform >= 0.5), px [B] its accept probability, x_out [B][x_dim] = Lx where px - u >= 0 else x. */
-/* Tuning / diagnostic knob of the toy-target kernel (no reference counterpart): its first layer runs on the matrix
- * pipe for batches of at most one wave per SIMD (<= 16384 rows) and on the VALU for larger ones; the two forms walk
- * the hidden layer's k in different orders and agree to rounding.  1 / 2 force the matrix / VALU form for every batch,
- * 0 restores the choice by size. */
-int l2hmc_small_first_layer_form(int32_t form);
-
 int l2hmc_small_propose(const l2hmc_small_plan* plan, const float* x, int64_t B, uint64_t seed, uint64_t draw0,
                         float* Lx, float* Lv, float* px, float* x_out, l2hmc_stream_t stream);
 

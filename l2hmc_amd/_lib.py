@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 MAX_MIX, MAX_SMALL_DIM = 8, 8
-PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY, PLAN_RECOMPUTE = 1, 2, 4, 8
+PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY, PLAN_RECOMPUTE, PLAN_TILES16_ONLY, PLAN_ALL_COLUMNS = 1, 2, 4, 8, 16, 32
 GRAD_BUCKET_REST = 6
 BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 
@@ -57,7 +57,7 @@ class MogTarget(C.Structure):
 
 class SmallPlan(C.Structure):
     _fields_ = [("x_dim", C.c_int32), ("num_nodes", C.c_int32), ("trajectory_length", C.c_int32),
-                ("hmc", C.c_int32), ("eps", C.c_float), ("reserved", C.c_float), ("masks", c_float_p),
+                ("hmc", C.c_int32), ("eps", C.c_float), ("first_layer_form", C.c_int32), ("masks", c_float_p),
                 ("xnet", DenseNet), ("vnet", DenseNet), ("target", MogTarget)]
 
 
@@ -82,6 +82,7 @@ _PROTOS = {
     "l2hmc_mix_accept": (C.c_int, [_P] * 9 + [_I32, _I64, _I32, _P, _P, _P, _P, _P]),
     "l2hmc_gauge_ws_bytes": (_SZ, [C.POINTER(GaugePlan), _I64]),
     "l2hmc_gauge_plan_fused": (C.c_int, [C.POINTER(GaugePlan)]),
+    "l2hmc_gauge_step_plan": (C.c_int, [_I64, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "l2hmc_gauge_leapfrog": (C.c_int, [C.POINTER(GaugePlan), _F, _I32, _P, _P, _P, _I64, _P, _P, _SZ, _P]),
     "l2hmc_gauge_trajectory": (C.c_int, [C.POINTER(GaugePlan), _F, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                          _SZ, _P]),
@@ -112,7 +113,6 @@ _PROTOS = {
     "l2hmc_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _I64, _I64, _P]),
     "l2hmc_mog_energy_grad": (C.c_int, [C.POINTER(MogTarget), _P, _I64, _P, _P, _P]),
     "l2hmc_small_trajectory": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
-    "l2hmc_small_first_layer_form": (C.c_int, [_I32]),
     "l2hmc_small_propose": (C.c_int, [C.POINTER(SmallPlan), _P, _I64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     "l2hmc_small_train_ws_bytes": (_SZ, [C.POINTER(SmallPlan), _I64]),
     "l2hmc_small_train_step": (C.c_int, [C.POINTER(SmallPlan), _P, _P, _P, _I64, _F, _F, _P, _P, _P, _P, _P, _P, _SZ,

@@ -44,7 +44,7 @@ struct FusedArgs {
 // the sub-tile form (fused_traj4.hip): GenericNet 8x8 plans, sampling only
 size_t fused4_pack_floats(const l2hmc_dense_net* n);                 // floats of its weight image (appended to the 16-row image)
 int launch_fused4_pack(const l2hmc_dense_net* n, float* image4, hipStream_t stream);
-int fused4_rows_per_wg(int64_t rows);                                // 0: use the 16-row form; else 4 or 8
+int fused4_rows_per_wg(int64_t rows, int cus);                       // 0: use the 16-row form; else 4, 8 or 12 (at most one workgroup per CU)
 int launch_fused4(const FusedArgs& a, int rows_per_wg, hipStream_t stream);
 
 // the 32-row form (fused_traj32.hip): same plans, same packed image as the 16-row form; for batches of more than one

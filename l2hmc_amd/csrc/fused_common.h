@@ -57,23 +57,71 @@ __device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restri
   for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
 }
 
-// DEPTH-deep ring of B fragments: chunk kc + DEPTH is requested as soon as chunk kc has been consumed, so every
-// load has DEPTH - 1 full MFMA blocks (32 x NT cycles each) to come back from L2 -- measured under this kernel's
-// load an L2 hit takes ~1,300 cycles, so 8-tile layers want DEPTH >= 3 and the 6-tile heads DEPTH >= 4.  The ring
-// of the NEXT layer is primed before the current layer's epilogue and barrier, which hides the pipeline fill.
+// Ring of B fragments, DEPTH slots of NT fragments; chunk k of the walk lives in slot k % DEPTH and every slot is
+// re-loaded IN PLACE (same registers: the allocator never has to rotate the ring), but not behind its block as in
+// rounds 1-3: left to itself the compiler sank those loads into bursts of 2 * NT behind the FOLLOWING block and
+// drained the queue in front of it (ISA of rounds 1-3) -- the wave issued 16 loads back to back while its matrix pipe
+// idled, 38 cycles per v_mfma_f32_16x16x4_f32.  Now a block runs in two halves over its tile groups [0, NT / 2) and
+// [NT / 2, NT), the order fixed by sched_barrier, with ONE 1 KiB load after every fourth MFMA:
+//   first half  (MFMAs on group 0): the previous block's group-1 registers take their next chunk,
+//   second half (MFMAs on group 1): this block's own group-0 registers take theirs.
+// A load issues while the pipe works on the four MFMAs in front of it: 34-35 cycles per MFMA in isolation
+// (tools/mfma_pinned_bench.hip, profiles/r04_mfma_pinned_bench.txt; an LDS ring fed by LDS-DMA loader waves reads 41
+// cycles on the consumer side alone and 57-73 with its hand-shake: not built).  Every fragment has DEPTH - 1 blocks
+// (32 x NT cycles each) to come back from L2.  The ring of the NEXT layer is primed before the current layer's
+// epilogue and barrier, which hides the pipeline fill.
 template <int NT, int DEPTH = 3>
 struct BRing {
   f32x4 b[DEPTH][NT];
 };
 
+template <int NT, int T0, int T1>
+__device__ __forceinline__ void load_group(f32x4 (&b)[NT], const float* __restrict__ wp, int kc) {
+#pragma unroll
+  for (int t = T0; t < T1; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
+}
+
 // rev: the layer's k-chunks are walked from the last to the first (NKC chunks in all).  A network's image is
 // streamed in alternating directions on its consecutive calls, so the part of it that the previous call left in L2
 // -- its most recently touched end -- is what the next call asks for first.
+// Primes chunks 0 .. DEPTH - 1 of the walk except the last slot's second tile group, which the first block requests.
 template <int NT, int DEPTH>
 __device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp, bool rev = false,
                                            int nkc = 0) {
 #pragma unroll
-  for (int s = 0; s < DEPTH; ++s) load_frags<NT>(R.b[s], wp, rev ? nkc - 1 - s : s);
+  for (int s = 0; s < DEPTH - 1; ++s) load_frags<NT>(R.b[s], wp, rev ? nkc - 1 - s : s);
+  load_group<NT, 0, (NT + 1) / 2>(R.b[DEPTH - 1], wp, rev ? nkc - DEPTH : DEPTH - 1);
+}
+
+// Half a block: acc[t] += cur[t] (x) a over the chunk's four k-steps for the tiles [T0, T1), e-major (every
+// accumulator sees its k in ascending order: the bits do not depend on the interleave); after every fourth MFMA one
+// of the fragments [L0, L1) of chunk `kc` goes into dst (LOAD); an odd tile count leaves one more load than the
+// shorter half has slots: it goes behind the last MFMA.
+// G groups of MPL MFMAs, one load behind each of the first NLD groups (all that are left behind the last one)
+template <int G, int NLD, int MPL = 4, int g = 0>
+__device__ __forceinline__ void sched_mfma_load_pipeline() {
+  if constexpr (g < G) {
+    __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);                                   // MPL MFMA
+    if constexpr (g < NLD) __builtin_amdgcn_sched_group_barrier(0x020, g == G - 1 ? NLD - g : 1, 0);   // VMEM read(s)
+    sched_mfma_load_pipeline<G, NLD, MPL, g + 1>();
+  }
+}
+
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD>
+__device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
+                                                 f32x4 (&acc)[NT], const float* __restrict__ wp, int kc) {
+  constexpr int G = T1 - T0, NLD = L1 - L0;
+#pragma unroll
+  for (int i = 0; i < 4 * G; ++i) {
+    const int e = i / G, t = T0 + i % G;
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][e], a[e], acc[t], 0, 0, 0);
+  }
+  if constexpr (LOAD) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + L0 + j) * 256);
+  }
+  // the order the scheduler must emit: four MFMAs, one load, four MFMAs, one load, ...
+  sched_mfma_load_pipeline<G, LOAD ? NLD : 0>();
 }
 
 // wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
@@ -81,25 +129,35 @@ __device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __r
 template <int NT, int NKC, int DEPTH, typename AF>
 __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wp, AF afrag,
                                              f32x4 (&acc)[NT], bool rev = false) {
-  static_assert(NKC >= DEPTH, "ring depth");
+  static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
+  constexpr int G = (NT + 1) / 2;                              // tiles [0, G) and [G, NT)
   auto km = [&](int k) { return rev ? NKC - 1 - k : k; };      // position in the walk -> chunk
+  // block k requests group 1 of chunk k + DEPTH - 1 (first half) and group 0 of chunk k + DEPTH (second half)
+  constexpr int MAIN = (NKC - DEPTH) / DEPTH * DEPTH;          // rolled loop: both requests in range
   f32x4 a0 = afrag(km(0));
   int kc = 0;
 #pragma nounroll
-  for (; kc + DEPTH <= NKC; kc += DEPTH) {
+  for (; kc < MAIN; kc += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
-      const f32x4 a1 = afrag(km(kc + s + 1 < NKC ? kc + s + 1 : NKC - 1));
-      mfma_block<NT>(a0, R.b[s], acc);
-      if (kc + s + DEPTH < NKC) load_frags<NT>(R.b[s], wp, km(kc + s + DEPTH));
+      const f32x4 a1 = afrag(km(kc + s + 1));
+      mfma_half_stream<NT, 0, G, G, NT, true>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(kc + s + DEPTH - 1));
+      mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(kc + s + DEPTH));
       a0 = a1;
     }
   }
-  constexpr int REM = NKC % DEPTH;        // their fragments were requested by the last full round
 #pragma unroll
-  for (int s = 0; s < REM; ++s) {
-    const f32x4 a1 = afrag(km(NKC - REM + s + 1 < NKC ? NKC - REM + s + 1 : NKC - 1));
-    mfma_block<NT>(a0, R.b[s], acc);
+  for (int k = MAIN; k < NKC; ++k) {                           // the walk's end: compile-time block numbers
+    const int s = (k - MAIN) % DEPTH;
+    const f32x4 a1 = afrag(km(k + 1 < NKC ? k + 1 : NKC - 1));
+    if (k + DEPTH - 1 < NKC)
+      mfma_half_stream<NT, 0, G, G, NT, true>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(k + DEPTH - 1));
+    else
+      mfma_half_stream<NT, 0, G, G, NT, false>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, 0);
+    if (k + DEPTH < NKC)
+      mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(k + DEPTH));
+    else
+      mfma_half_stream<NT, G, NT, 0, G, false>(a0, R.b[s], R.b[s], acc, wp, 0);
     a0 = a1;
   }
 }

@@ -167,12 +167,14 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   const int nrow = (int)min((int64_t)kFM, p.rows - row0);
   const float eps = p.eps;
 
+#ifdef L2HMC_STAMPS
   if (p.stagger > 0) {
-    // spread the workgroups of an XCD (blockIdx & 7 labels the XCD group) over the weight stream in time
+    // (diagnostic build) spread the workgroups of an XCD (blockIdx & 7 labels the XCD group) over the weight stream
     const long long delay = (long long)((blockIdx.x >> 3) & 31) * p.stagger;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
   }
+#endif
   // ---- stage chain state and constants ------------------------------------
   const bool STEPM = p.step_B > 0;
   const int cpw = STEPM ? (p.step_both ? kFM / 2 : kFM) : kFM;           // chains per workgroup in step mode
@@ -928,17 +930,8 @@ static int fused_conv_net(const l2hmc_dense_net* n) {
 }
 int fused_net_supported(const l2hmc_dense_net* n) { return fused_generic_net(n) || fused_conv_net(n); }
 
-// L2HMC_FUSED_SUBTILE=0 keeps every batch on the 16-row form (A/B and the bit-identity test)
-static std::atomic<int> g_subtile{-1};
-static bool subtile_enabled() {
-  int v = g_subtile.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("L2HMC_FUSED_SUBTILE");
-    v = (e && e[0] == '0') ? 0 : 1;
-    g_subtile.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
+// L2HMC_PLAN_TILES16_ONLY keeps every batch on the 16-row form (A/B and the bit-identity test)
+static bool subtile_enabled(const l2hmc_gauge_plan* p) { return !(p->flags & L2HMC_PLAN_TILES16_ONLY); }
 // CUs of the current device (one 16-row workgroup each per round); asked once per device
 static int device_cu_count() {
   static std::atomic<int> cached[16];
@@ -951,11 +944,6 @@ static int device_cu_count() {
   }
   return n;
 }
-extern "C" int l2hmc_debug_fused_subtile(int on) {
-  g_subtile.store(on ? 1 : 0, std::memory_order_relaxed);
-  return 0;
-}
-
 int fused_plan_supported(const l2hmc_gauge_plan* p) {
   if (p->hmc || !p->xnet.packed || !p->vnet.packed || 2 * p->T * p->X != 128 || (p->X & (p->X - 1)) != 0) return 0;
   if (p->flags & L2HMC_PLAN_CONV3D)
@@ -1021,8 +1009,8 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.stagger = g_fused_stagger;
 #endif
   // batches that cannot put a 16-row tile on every CU: the sub-tile form (4 or 8 rows per workgroup, same bits)
-  if (!conv && !tape && subtile_enabled()) {
-    if (const int rpw = fused4_rows_per_wg(rows)) return launch_fused4(a, rpw, stream);
+  if (!conv && !tape && subtile_enabled(p)) {
+    if (const int rpw = fused4_rows_per_wg(rows, device_cu_count())) return launch_fused4(a, rpw, stream);
     // more than one round of 16-row workgroups: the 32-row form (each weight fragment feeds two MFMAs)
     if (rows > (int64_t)kFM * device_cu_count()) return launch_fused32(a, stream);
   }
@@ -1049,29 +1037,33 @@ static int plan_step_parts(int64_t rows_all, bool forms, int cus, StepPart (&par
   int n = 0;
   if (!forms) {
     parts[n++] = {rows_all, kFM};
-  } else if (const int all = fused4_rows_per_wg(rows_all)) {
+  } else if (const int all = fused4_rows_per_wg(rows_all, cus)) {
     parts[n++] = {rows_all, all};
   } else {
     const int64_t round16 = (int64_t)kFM * cus;                          // rows in one full round of 16-row workgroups
     const int64_t main32 = rows_all / (2 * round16) * (2 * round16), rem = rows_all - main32;
     const int64_t over = rem - round16;                                  // rows beyond one more 16-row round
-    if (rem > round16 && !(over <= 2048 && fused4_rows_per_wg(over))) {
+    if (rem > round16 && !(over <= 8 * (int64_t)cus && fused4_rows_per_wg(over, cus))) {
       parts[n++] = {rows_all, 32};                                       // the rest fills most of another 32-row round
     } else {
       if (main32 > 0) parts[n++] = {main32, 32};
       if (rem > round16) {
         parts[n++] = {round16, kFM};
-        parts[n++] = {over, fused4_rows_per_wg(over)};
+        parts[n++] = {over, fused4_rows_per_wg(over, cus)};
       } else if (rem > 0) {
-        const int sub = fused4_rows_per_wg(rem);
+        const int sub = fused4_rows_per_wg(rem, cus);
         parts[n++] = {rem, sub ? sub : kFM};
       }
     }
   }
   return n;
 }
-// test hook (host logic only, no device call; include/ does not declare it): the plan for `rows_all` rows on `cus` CUs
-extern "C" int l2hmc_debug_step_plan(int64_t rows_all, int cus, int64_t* rows_out, int* rpw_out) {
+// host logic only, no device call: the launch plan for `rows_all` rows on `cus` CUs
+extern "C" int l2hmc_gauge_step_plan(int64_t rows_all, int32_t cus, int64_t* rows_out, int32_t* rpw_out) {
+  if (rows_all <= 0 || cus <= 0 || !rows_out || !rpw_out) {
+    set_error("gauge_step_plan: rows_all=%lld cus=%d (both > 0) and two output arrays of 3 entries", (long long)rows_all, cus);
+    return L2HMC_ERR_ARG;
+  }
   StepPart parts[3];
   const int n = plan_step_parts(rows_all, true, cus, parts);
   for (int i = 0; i < n; ++i) {
@@ -1114,7 +1106,7 @@ int launch_fused_step(const l2hmc_gauge_plan* p, float beta, const float* x_in, 
   //   - a batch that is small as a whole is one sub-tile launch, a batch of at most one round one 16-row launch.
   const int ndir = both ? 2 : 1;
   StepPart parts[3];
-  const int nparts = plan_step_parts(B * ndir, !conv && subtile_enabled(), device_cu_count(), parts);
+  const int nparts = plan_step_parts(B * ndir, !conv && subtile_enabled(p), device_cu_count(), parts);
   auto part_of = [&](int64_t c0, int64_t nb, int rpw, int accumulate) {
     const int cpw = both ? rpw / 2 : rpw;
     const int64_t D = 2 * (int64_t)p->T * p->X;

@@ -33,17 +33,24 @@ constexpr int kNC = 4 * kH + 5 * kD;
 constexpr int kTPC = 16;                                   // threads per chain in the chain-local passes (two passes of 16 chains)
 constexpr int kLds32 = 3 * kR32 * kSX + kR32 * kSH + 2 * kNC + kR32 * kSP + 2 * kD + kW32 * kR32 + kR32 + 8 * kR32;
 
-// both row groups' products of one 16-k chunk: every weight fragment b[t] feeds two MFMAs
-template <int NT>
-__device__ __forceinline__ void mfma_block2(const f32x4 a0, const f32x4 a1, const f32x4 (&b)[NT], f32x4 (&acc0)[NT],
-                                            f32x4 (&acc1)[NT]) {
+// Half a block for both row groups (fused_common.h: mfma_half_stream): every weight fragment cur[t] feeds two MFMAs,
+// so one load goes behind every EIGHTH MFMA.  e-major per accumulator, as the 16-row form.
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD>
+__device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
+                                                  f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const float* __restrict__ wp, int kc) {
+  constexpr int G = T1 - T0, NLD = L1 - L0;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][e], a0[e], acc0[t], 0, 0, 0);
-      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][e], a1[e], acc1[t], 0, 0, 0);
+    for (int t = T0; t < T1; ++t) {
+      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][e], a0[e], acc0[t], 0, 0, 0);
+      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][e], a1[e], acc1[t], 0, 0, 0);
     }
+  if constexpr (LOAD) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + L0 + j) * 256);
+  }
+  sched_mfma_load_pipeline<G, LOAD ? NLD : 0, 8>();
 }
 
 // stream_layer (fused_common.h) for two row groups; ap = the lane's fragment address in row group 0, gstride = floats
@@ -51,29 +58,39 @@ __device__ __forceinline__ void mfma_block2(const f32x4 a0, const f32x4 a1, cons
 template <int NT, int NKC, int DEPTH>
 __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* __restrict__ wp, const float* ap,
                                               int gstride, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], bool rev = false) {
-  static_assert(NKC >= DEPTH, "ring depth");
+  static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
+  constexpr int G = (NT + 1) / 2;
   auto km = [&](int k) { return rev ? NKC - 1 - k : k; };
   auto af = [&](int kc, int g) { return *reinterpret_cast<const f32x4*>(ap + g * gstride + kc * 16); };
+  constexpr int MAIN = (NKC - DEPTH) / DEPTH * DEPTH;
   f32x4 a0 = af(km(0), 0), c0 = af(km(0), 1);
   int kc = 0;
 #pragma nounroll
-  for (; kc + DEPTH <= NKC; kc += DEPTH) {
+  for (; kc < MAIN; kc += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
-      const int kn = km(kc + s + 1 < NKC ? kc + s + 1 : NKC - 1);
+      const int kn = km(kc + s + 1);
       const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
-      mfma_block2<NT>(a0, c0, R.b[s], acc0, acc1);
-      if (kc + s + DEPTH < NKC) load_frags<NT>(R.b[s], wp, km(kc + s + DEPTH));
+      mfma_half_stream2<NT, 0, G, G, NT, true>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
+                                               km(kc + s + DEPTH - 1));
+      mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(kc + s + DEPTH));
       a0 = a1;
       c0 = c1;
     }
   }
-  constexpr int REM = NKC % DEPTH;
 #pragma unroll
-  for (int s = 0; s < REM; ++s) {
-    const int kn = km(NKC - REM + s + 1 < NKC ? NKC - REM + s + 1 : NKC - 1);
+  for (int k = MAIN; k < NKC; ++k) {
+    const int s = (k - MAIN) % DEPTH;
+    const int kn = km(k + 1 < NKC ? k + 1 : NKC - 1);
     const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
-    mfma_block2<NT>(a0, c0, R.b[s], acc0, acc1);
+    if (k + DEPTH - 1 < NKC)
+      mfma_half_stream2<NT, 0, G, G, NT, true>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, km(k + DEPTH - 1));
+    else
+      mfma_half_stream2<NT, 0, G, G, NT, false>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, 0);
+    if (k + DEPTH < NKC)
+      mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(k + DEPTH));
+    else
+      mfma_half_stream2<NT, G, NT, 0, G, false>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, 0);
     a0 = a1;
     c0 = c1;
   }

@@ -664,12 +664,12 @@ int launch_fused4_pack(const l2hmc_dense_net* n, float* image4, hipStream_t stre
 }
 
 // rows per workgroup of the sub-tile form, or 0 where 16-row tiles already cover the CUs
-int fused4_rows_per_wg(int64_t rows) {
+int fused4_rows_per_wg(int64_t rows, int cus) {
   // (measured and dropped: two 4-row workgroups per CU for 1024 < rows <= 2048 -- 512 workgroups streaming the weights
   //  ask the L2s for ~55 TB/s: 1.61 ms against 1.07 ms for one 8-row workgroup per CU)
-  if (rows <= 4 * 256) return 4;
-  if (rows <= 8 * 256) return 8;
-  if (rows <= 12 * 256) return 12;
+  if (rows <= 4 * (int64_t)cus) return 4;
+  if (rows <= 8 * (int64_t)cus) return 8;
+  if (rows <= 12 * (int64_t)cus) return 12;
   return 0;
 }
 

@@ -270,13 +270,6 @@ static int check_plan(const l2hmc_gauge_plan* p) {
   return L2HMC_OK;
 }
 
-// test / A-B hook (include/ does not declare it): 0 = every heads launch forms all columns
-static std::atomic<int> g_heads_active_cols{1};
-extern "C" int l2hmc_debug_heads_active_cols(int on) {
-  g_heads_active_cols.store(on ? 1 : 0, std::memory_order_relaxed);
-  return 0;
-}
-
 // one S/T/Q evaluation of `net` on (a, b*mask), fused with the v or x update
 static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, const float* a,
                       const float* b, const float* cm_f, const float* cm_b, const int* dir,
@@ -334,7 +327,7 @@ static int net_update(const l2hmc_gauge_plan* plan, const l2hmc_dense_net* net, 
   h.q_tanh = net->q_tanh; h.D = net->D; h.rows = rows; h.mode = mode;
   h.x = x; h.v = v; h.g = g; h.dir = dir; h.keep_f = keep_f; h.keep_b = keep_b; h.eps = eps;
   h.ld_part = w.ld_part; h.ncb = ncb;
-  if (mode == 2 && dir_split >= 0 && g_heads_active_cols.load(std::memory_order_relaxed)) {
+  if (mode == 2 && dir_split >= 0 && !(plan->flags & L2HMC_PLAN_ALL_COLUMNS)) {
     // only the columns this sub-update moves (the others' S, T, Q are multiplied by 1 - keep = 0)
     h.cols_f = cols_f; h.cols_b = cols_b; h.cnt_f = cnt_f; h.cnt_b = cnt_b; h.dir_split = dir_split;
   }

@@ -626,11 +626,10 @@ static int launch_small_mfma_form(const SmallTrajArgs& a, dim3 grid, hipStream_t
 }
 
 // first layer on the matrix pipe while every wave has a SIMD to itself (<= 1024 waves of 16 chains), on the VALU for
-// larger batches; l2hmc_small_first_layer_form forces one form (they agree to rounding: tests)
-static std::atomic<int> g_small_l1_form{0};
+// larger batches; l2hmc_small_plan::first_layer_form forces one form (they agree to rounding: tests)
 template <int HP, int MD, int KS_, int KSH_>
 static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
-  const int force = g_small_l1_form.load(std::memory_order_relaxed);
+  const int force = a.plan.first_layer_form;
   const bool l1m = force ? force == 1 : ceil_div(a.rows, 16) <= 1024;
   return l1m ? launch_small_mfma_form<HP, MD, KS_, KSH_, true>(a, grid, st)
              : launch_small_mfma_form<HP, MD, KS_, KSH_, false>(a, grid, st);
@@ -649,12 +648,6 @@ static int check_target(const l2hmc_mog_target* t) {
 }  // namespace l2hmc
 
 using namespace l2hmc;
-
-extern "C" int l2hmc_small_first_layer_form(int32_t form) {
-  L2HMC_REQUIRE(form >= 0 && form <= 2, "small_first_layer_form: 0 (by batch size), 1 (matrix pipe) or 2 (VALU)");
-  g_small_l1_form.store(form, std::memory_order_relaxed);
-  return L2HMC_OK;
-}
 
 extern "C" int l2hmc_mog_energy_grad(const l2hmc_mog_target* tgt, const float* x, int64_t rows, float* energy,
                                      float* grad, l2hmc_stream_t stream) {
@@ -704,6 +697,8 @@ static int small_launch(const l2hmc_small_plan* plan, SmallTrajArgs a, l2hmc_str
   const int dim = plan->x_dim, H = plan->num_nodes, N = plan->trajectory_length;
   L2HMC_REQUIRE(dim == plan->target.dim, "small_trajectory: x_dim=%d != target dim=%d", dim, plan->target.dim);
   L2HMC_REQUIRE(N > 0 && plan->masks != nullptr, "small_trajectory: bad trajectory_length / masks");
+  L2HMC_REQUIRE(plan->first_layer_form >= 0 && plan->first_layer_form <= 2,
+                "small_trajectory: first_layer_form=%d (0 by batch size, 1 matrix pipe, 2 VALU)", plan->first_layer_form);
   const int64_t rows = a.rows;
   if (!plan->hmc) {
     L2HMC_REQUIRE(H > 0 && H <= 64, "small_trajectory: num_nodes=%d unsupported (1..64)", H);

@@ -15,22 +15,35 @@ from . import _lib
 
 class _PackedTarget:
     def __init__(self, mus, precs, log_consts, is_gaussian, device=None):
-        self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.K, self.dim = len(mus), int(np.asarray(mus[0]).shape[0])
         if self.dim > _lib.MAX_SMALL_DIM or self.K > _lib.MAX_MIX:
             raise ValueError(f"target: dim={self.dim} / K={self.K} beyond the fused kernel's limits "
                              f"({_lib.MAX_SMALL_DIM}, {_lib.MAX_MIX})")
         self.is_gaussian = int(is_gaussian)
-        self.mu = _lib.as_dev(np.stack([np.asarray(m, dtype=np.float32) for m in mus]), self.device)
-        self.prec = _lib.as_dev(np.stack([np.asarray(p, dtype=np.float32) for p in precs]), self.device)
-        self.log_const = _lib.as_dev(np.asarray(log_consts, dtype=np.float32), self.device)
+        self._host = (np.stack([np.asarray(m, dtype=np.float32) for m in mus]),
+                      np.stack([np.asarray(p, dtype=np.float32) for p in precs]),
+                      np.asarray(log_consts, dtype=np.float32))
+        self.device = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        """Parameters onto `device` (done on first use with the current CUDA device when nobody asked earlier)."""
+        if self.device != device:
+            self.device = device
+            self.mu, self.prec, self.log_const = (_lib.as_dev(a, device) for a in self._host)
+        return self
 
     def struct(self, temperature=1.0):
+        if self.device is None:
+            self.to(torch.device("cuda", torch.cuda.current_device()))
         return _lib.MogTarget(dim=self.dim, K=self.K, is_gaussian=self.is_gaussian,
                               temperature=float(temperature), mu=self.mu.data_ptr(),
                               prec=self.prec.data_ptr(), log_const=self.log_const.data_ptr())
 
     def energy_grad(self, x, temperature=1.0, want_grad=True):
+        if self.device is None:
+            self.to(torch.device("cuda", torch.cuda.current_device()))
         x = _lib.as_dev(x, self.device).reshape(-1, self.dim)
         e = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         g = torch.empty_like(x) if want_grad else None

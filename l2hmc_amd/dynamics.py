@@ -15,6 +15,7 @@ class Dynamics(object):
         self.x_dim = x_dim
         self.use_temperature = use_temperature
         self.temperature = 1.0             # the reference feeds a placeholder (:48)
+        self.first_layer_form = 0          # 0 by batch size; 1 / 2 force the toy kernel's matrix-pipe / VALU first layer
         self._device = device or torch.device("cuda", torch.cuda.current_device())
         # quirk Q2: eps = exp(alpha), alpha = log(eps) (:51-60)
         self.alpha = torch.log(torch.tensor(float(eps), dtype=torch.float32))
@@ -27,6 +28,7 @@ class Dynamics(object):
                             "Python callables cannot run inside the fused trajectory kernel")
         if self._target.dim != x_dim:
             raise ValueError(f"x_dim={x_dim} but the target has dimension {self._target.dim}")
+        self._target.to(self._device)
         self.trajectory_length = int(trajectory_length)
         self.hmc = hmc
         self._init_mask()
@@ -90,7 +92,7 @@ class Dynamics(object):
 
     def _plan(self):
         p = _lib.SmallPlan(x_dim=self.x_dim, trajectory_length=self.trajectory_length, hmc=int(bool(self.hmc)),
-                           eps=float(self.eps), reserved=0., masks=self.mask.data_ptr(),
+                           eps=float(self.eps), first_layer_form=int(self.first_layer_form), masks=self.mask.data_ptr(),
                            target=self._target.struct(self._temp()), num_nodes=0)
         if not self.hmc:
             p.xnet, p.vnet = self.XNet.pack(), self.VNet.pack()

@@ -35,6 +35,8 @@ class GaugeDynamics:
         self.fused = True                # whole-trajectory kernel where the shape has one
         self.check_numerics = False      # True: raise on a non-finite trajectory like tf.check_numerics (:26-28)
         self.recompute = False           # True: layer-by-layer path forms every first-layer product anew (diagnostic)
+        self.tiles16_only = False        # True: whole-step kernel on its 16-row form for every batch (A/B, bit-identity test)
+        self.all_columns = False         # True: layer-by-layer path forms S/T/Q for every column of a position sub-update
         for key, val in kwargs.items():
             if key != 'eps':             # :73-75
                 setattr(self, key, val)
@@ -133,7 +135,9 @@ class GaugeDynamics:
                            hmc=int(bool(self.hmc)), eps=float(self.eps),
                            flags=(0 if self.fused else _lib.PLAN_LAYERED)
                            | (0 if self.both_directions else _lib.PLAN_SELECTED_ONLY)
-                           | (_lib.PLAN_RECOMPUTE if self.recompute else 0),
+                           | (_lib.PLAN_RECOMPUTE if self.recompute else 0)
+                           | (_lib.PLAN_TILES16_ONLY if self.tiles16_only else 0)
+                           | (_lib.PLAN_ALL_COLUMNS if self.all_columns else 0),
                            masks=_lib.dev_ptr(self.mask, name="mask"))
         if not self.hmc:
             p.xnet = self.position_fn.pack()

@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol(L):
     assert L.l2hmc_abi_version() == 1
 
 
+def test_library_exports_nothing_the_header_does_not_declare(L):
+    """The shipped library carries no test / debug hooks: every exported C symbol `l2hmc_*` is declared in
+    include/l2hmc_hip.h (run-time switches are plan flags or plan fields), and the library reads no environment
+    variable."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("l2hmc_")}
+    assert exported == set(_lib.declared_symbols()), sorted(exported ^ set(_lib.declared_symbols()))
+    assert not [s for s in exported if "debug" in s]
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in und
+
+
 def test_struct_layouts_match_the_c_header(tmp_path):
     """sizeof/offsetof as gcc sees include/l2hmc_hip.h vs the ctypes mirrors: a mismatch would corrupt every call."""
     import subprocess
@@ -148,9 +161,7 @@ def test_step_launch_plan_covers_every_batch(L):
     rows exactly once, cuts at even row counts (both directions of a chain stay in one workgroup), uses the
     sub-tile form only where it has a workgroup per CU or fewer, and never needs more rounds than 16-row tiles
     alone would."""
-    fn = L.l2hmc_debug_step_plan
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    fn = L.l2hmc_gauge_step_plan
     rows_out, rpw_out = (C.c_int64 * 3)(), (C.c_int * 3)()
     cus = 256
     t16, t32 = 1.0, 1.8                                   # one round of 16-row / 32-row workgroups (measured 1.59 / 2.86 ms)

@@ -570,8 +570,8 @@ def test_both_first_layer_forms_of_the_toy_kernel_agree(la, name, B):
     v = torch.as_tensor(rng.standard_normal((B, 2)), dtype=torch.float32, device="cuda")
     outs = {}
     try:
-        for form in (1, 2, 1):                  # 1 = matrix pipe, 2 = VALU
-            _lib.check(_lib.lib().l2hmc_small_first_layer_form(form))
+        for form in (1, 2, 1):                  # 1 = matrix pipe, 2 = VALU (l2hmc_small_plan::first_layer_form)
+            dyn.first_layer_form = form
             dyn._draws = 20
             Lx, _, px, mh = la.propose(x, dyn, do_mh_step=False)
             Xf, Vf, pf = dyn.forward(x, init_v=v)
@@ -581,7 +581,7 @@ def test_both_first_layer_forms_of_the_toy_kernel_agree(la, name, B):
                 assert all(torch.equal(a, b) for a, b in zip(now, outs[form]))
             outs[form] = now
     finally:
-        _lib.check(_lib.lib().l2hmc_small_first_layer_form(0))
+        dyn.first_layer_form = 0
     errs = [H.relerr(np_(a), np_(b)) for a, b in zip(outs[1], outs[2])]
     print("toy kernel, matrix-pipe vs VALU first layer:", " ".join(f"{e:.1e}" for e in errs))
     # two fp32 summation orders of the same N-step trajectory (measured: profiles/r03_gate_envelope.txt)
@@ -1361,17 +1361,16 @@ def test_active_column_heads_equal_all_columns(la, L, arch, N, B):
     dyn = H.gauge_hip(L, L, N, 0.15, xp, vp, orc.mask, B, arch=arch)
     dyn.fused = False
     x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * L * L, seed=313)
-    Lh = _lib.lib()
     outs = {}
     try:
         for on in (1, 0):
-            Lh.l2hmc_debug_heads_active_cols(on)
+            dyn.all_columns = not on                     # L2HMC_PLAN_ALL_COLUMNS
             f = dyn.transition_kernel(x, 2.0, forward=True, momentum=v0f, return_logdet=True)
             tr = dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
             lf = dyn._forward_lf(x, v0f, 2.0, 1)
             outs[on] = (f, tr, lf)
     finally:
-        Lh.l2hmc_debug_heads_active_cols(1)
+        dyn.all_columns = False
     (f1, tr1, lf1), (f0, tr0, lf0) = outs[1], outs[0]
     assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])                  # x, v of the forward trajectory
     assert torch.equal(lf1[0], lf0[0]) and torch.equal(lf1[1], lf0[1])              # one leapfrog step
@@ -1407,14 +1406,13 @@ def test_active_column_heads_with_any_mask(la):
     dyn = H.gauge_hip(T, X, N, 0.1, xp, vp, masks, B)
     dyn.fused = False
     x, v0f, v0b, coin, u = H.gauge_inputs(B, D, seed=317)
-    Lh = _lib.lib()
     outs = {}
     try:
         for on in (1, 0):
-            Lh.l2hmc_debug_heads_active_cols(on)
+            dyn.all_columns = not on
             outs[on] = dyn.apply_transition(x, 2.0, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
     finally:
-        Lh.l2hmc_debug_heads_active_cols(1)
+        dyn.all_columns = False
     for a, b in ((outs[1][0], outs[0][0]), (outs[1][1], outs[0][1]), (outs[1][3], outs[0][3])):
         assert torch.equal(a, b)
     assert float((outs[1][2] - outs[0][2]).abs().max()) <= 1e-5
@@ -1444,11 +1442,10 @@ def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
     v = torch.as_tensor(rng.standard_normal((B, 128)), dtype=torch.float32, device="cuda")
     coin = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
     uu = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
-    L = _lib.lib()
     outs = {}
     try:
         for sub in (1, 0):
-            L.l2hmc_debug_fused_subtile(sub)
+            dyn.tiles16_only = not sub                   # L2HMC_PLAN_TILES16_ONLY
             dyn._draws = 40
             smp = GaugeSampler(dyn)
             xn, px, obs, dq = smp.step(x, beta)
@@ -1466,7 +1463,7 @@ def test_subtile_and_32_row_forms_equal_16_row_form(la, B):
             outs[sub] = [xn, px, obs["action"], obs["avg_plaq"], obs["top_charge"], dq, *tr, *f, *b, *lf, *sel, *inj,
                          smp.stats.mean_accept()]
     finally:
-        L.l2hmc_debug_fused_subtile(1)
+        dyn.tiles16_only = False
     for i, (a, b_) in enumerate(zip(outs[1][:-1], outs[0][:-1])):
         assert torch.equal(a, b_), f"output {i} differs between the sub-tile and the 16-row form"
     # the step's mean accept probability is a fixed-order sum of per-WORKGROUP partial sums: another grouping of the

@@ -85,6 +85,44 @@ def test_mask_and_time_tables_follow_reference_streams():
     assert a.sum() == 10 * 64 and set(np.unique(a)) == {0.0, 1.0}
 
 
+def test_product_constructors_draw_the_reference_mask_stream():
+    """Row a5 on the PRODUCT side (the parity tests inject the oracle's masks through set_masks): after
+    np.random.seed(42) -- gauge_model.py:195 -- `GaugeDynamics.__init__` (-> _construct_masks_while,
+    gauge_dynamics.py:651-661) must put the ones of its first mask row at the reference's indices
+    [55, 40, 19, 31, 98, 56, 69, 104, ...] (the frozen legacy NumPy stream), every row holding exactly
+    D // 2 ones; `Dynamics._init_mask` (utils/dynamics.py:85-96) draws the same stream for its x_dim."""
+    import l2hmc_amd as la
+    cpu = torch.device("cpu")
+    ref = np.random.RandomState(42)
+    want = [ref.permutation(128)[:64] for _ in range(10)]
+    assert list(want[0][:8]) == [55, 40, 19, 31, 98, 56, 69, 104]
+    for arch in ("generic", "conv3D"):
+        np.random.seed(42)
+        lat = la.GaugeLattice(8, 8, 2, 'U1', num_samples=4, rand=False)
+        dyn = la.GaugeDynamics(lat, lat.get_energy_function(), eps=0.25, hmc=False, network_arch=arch, num_steps=10,
+                               eps_trainable=True, data_format='channels_last', device=cpu)
+        m = dyn.mask.numpy()
+        assert m.shape == (10, 128) and m.dtype == np.float32 and set(np.unique(m)) == {0.0, 1.0}
+        for s in range(10):
+            assert sorted(np.flatnonzero(m[s])) == sorted(want[s]), s
+        keep, moved = dyn._get_mask_while(3)
+        np.testing.assert_array_equal(keep.numpy(), m[3])
+        np.testing.assert_array_equal(moved.numpy(), 1.0 - m[3])
+    # the generic integrator: x_dim = 2 -> one of the two coordinates per step, same stream
+    np.random.seed(42)
+    ref = np.random.RandomState(42)
+    want2 = [ref.permutation(2)[:1] for _ in range(10)]
+    tgt = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
+    d2 = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=10, eps=0.1, device=cpu,
+                     net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=10, device=cpu))
+    m2 = d2.mask.numpy()
+    assert m2.shape == (10, 2)
+    for s in range(10):
+        assert list(np.flatnonzero(m2[s])) == list(want2[s])
+        a, b = d2._get_mask(s)
+        np.testing.assert_array_equal(a.numpy() + b.numpy(), np.ones(2, np.float32))
+
+
 def test_ess_estimators_follow_reference_definitions():
     """func_utils.py:45-54,114-120 restated as loops here, vectorised in l2hmc_amd/stats.py."""
     from l2hmc_amd import stats

@@ -55,9 +55,13 @@ def gauge(name, L, B, N, eps, beta, arch, iters=5, fused=True):
     time.sleep(0.3)       # the release of the big layered workspaces otherwise runs into the next configuration's timing
 
 
+FIRST_LAYER_FORM = 0
+
+
 def small(name, target, B, N, H):
     dyn = la.Dynamics(2, target.get_energy_function(), trajectory_length=N, eps=0.1,
                       net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=H))
+    dyn.first_layer_form = FIRST_LAYER_FORM
     x = torch.randn(B, 2, device="cuda")
     dt = timeit(lambda: la.propose(x, dyn, do_mh_step=True), warm=3, iters=20)
     print(f"{name:46s} {dt*1e3:10.3f} ms/propose     useful {B*N/dt/1e6:8.3f} M chain-LF/s", flush=True)
@@ -112,7 +116,8 @@ def main():
         from l2hmc_amd import _lib
         print("library:", _lib.LIB_PATH)
         if len(sys.argv) > 2:               # 1: first layer on the matrix pipe, 2: on the VALU (default: by batch size)
-            _lib.check(_lib.lib().l2hmc_small_first_layer_form(int(sys.argv[2])))
+            global FIRST_LAYER_FORM
+            FIRST_LAYER_FORM = int(sys.argv[2])
             print("first-layer form forced to", {1: "matrix pipe", 2: "VALU"}[int(sys.argv[2])])
         scg = la.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
         mog = la.GMM([np.array([1., 0.]), np.array([0., 1.])], [0.025 * np.eye(2)] * 2, [0.5, 0.5])
