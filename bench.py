@@ -24,8 +24,13 @@ Default: weak for configs 1-3, strong for configs 4 and 5 (BASELINE.json names t
 8192 and 16384 chains over 8 GPUs = 1024 and 2048 per GPU; reference: gauge_model.py:942-943, 1008, 1095).
 
 Prints ONE JSON line (rank 0).  `value` counts USEFUL chain-leapfrog steps (chains x N_LF per step); the
-executed count is twice that (both directions) and is what the roofline FLOPs use.  A secondary leg that
-fails is reported under an "error" key AND makes the process exit non-zero after the line is printed.
+executed count is twice that (both directions) and is what the roofline FLOPs use.  Every `frac` / `tflops` /
+`achieved` in the line prices the FLOPs the kernels EXECUTE (recurring first-layer products are kept, position
+sub-updates form only the columns their mask lets move: `executed_macs_per_lf`) and can therefore never exceed 1;
+the reference graph's own count (every first layer and every head column formed anew) divided
+by the same time is reported beside it as `reference_flops_equiv_tflops` / `reference_flops_equiv_frac`.
+A secondary leg that fails is reported under an "error" key AND makes the process exit non-zero after the line is
+printed.
 """
 import argparse
 import ctypes as C
@@ -104,12 +109,25 @@ def executed_macs_per_lf(cfg, fused, active_cols):
     first momentum update of a trajectory).  active_cols (layer-by-layer path, rows' directions known per tile):
     the two position sub-updates form S / T / Q for the half of the columns they move."""
     c = CONFIGS[cfg]
-    _, d = config_macs(cfg)
+    m, d = config_macs(cfg)
+    if c["kind"] == "toy":             # the toy kernel evaluates every network call in full
+        return 4.0 * m
     D, H, N = d["D"], d["H"], c["N"]
     l1 = (d["Ka"] + d["Kb"]) * H + (conv_front_macs(c["L"], d["F"]) if c["arch"] == "conv3D" else 0)
     l1_calls = (2.5 * N + 1) / N
     heads_calls = 3.0 if active_cols else 4.0
     return l1_calls * l1 + 4 * (2 * H + H * H) + heads_calls * 3 * H * D
+
+
+def heads_use_active_columns(rows, D, H, dir_split):
+    """Mirror of csrc/stq_dense.hip:launch_heads for aligned shapes (every BASELINE config): does a position
+    sub-update over `rows` stacked rows (forward rows [0, dir_split), backward rows behind them) form S / T / Q only for
+    the columns its mask lets move?  The 128 x 64-tile form (grids of >= 512 tiles) needs the split on a 128-row edge,
+    the 64 x 32-tile form on a 64-row edge."""
+    split_ok = lambda bm: dir_split >= rows or dir_split % bm == 0      # noqa: E731
+    if H % 16 == 0 and D % 64 == 0 and -(-rows // 128) * (D // 64) >= 512:
+        return split_ok(128)
+    return split_ok(64)
 
 
 def rank_chains(cfg, world, rank, scaling):
@@ -231,7 +249,8 @@ def profile_class(Lh, cls, run, _lib):
 
 
 def gauge_kernel_classes(cfg, rows, fused, active_cols=False):
-    """(class id, kernel name, algorithmic FLOPs per launch) of the kernels a lattice step launches."""
+    """(class id, kernel name, EXECUTED FLOPs per launch, the reference graph's FLOPs for the same launch or None)
+    of the kernels a lattice step launches."""
     c = CONFIGS[cfg]
     macs, d = config_macs(cfg)
     D, H = d["D"], d["H"]
@@ -244,17 +263,19 @@ def gauge_kernel_classes(cfg, rows, fused, active_cols=False):
         name = ("gauge_traj_fused_kernel<128,512> (whole MCMC step in one launch: draws, both trajectories, "
                 "mix / MH, observables, wrap)" if c["arch"] == "generic" else
                 "gauge_traj_fused_kernel<128,256,64,conv> (whole MCMC step in one launch, conv front-end in LDS)")
-        return [(5, name, 8.0 * macs * rows * c["N"])]
+        # executed: the kernel keeps the recurring first-layer products in registers (2.5 N + 1 first layers per
+        # trajectory instead of 4 N); reference: every network call formed in full
+        return [(5, name, 2.0 * executed_macs_per_lf(cfg, True, False) * rows * c["N"], 8.0 * macs * rows * c["N"])]
     out = [(1, "gemm_relu_kernel<.,1> (first dense layer; average over whole and half-K launches)",
-            kept * 2.0 * rows * H * (d["Ka"] + d["Kb"])),
-           (2, "gemm_relu_kernel<.,2> (hidden dense layer)", 2.0 * rows * H * H),
+            kept * 2.0 * rows * H * (d["Ka"] + d["Kb"]), None),
+           (2, "gemm_relu_kernel<.,2> (hidden dense layer)", 2.0 * rows * H * H, None),
            (3, "heads_kernel (S/T/Q + sub-update + log-det; average over momentum updates -- all columns -- and "
                "position sub-updates -- the columns their keep mask lets move, where the rows' directions are known "
-               "per row tile)", (0.75 if active_cols else 1.0) * 2.0 * rows * 3 * D * H)]
+               "per row tile)", (0.75 if active_cols else 1.0) * 2.0 * rows * 3 * D * H, None)]
     if c["arch"] == "conv3D":
         out.append((6, "conv3d_front_kernel (both inputs: conv1+relu+pool, conv2+relu+pool; VALU, priced at the "
                        "fp32 MFMA rate; average over two-input and one-input launches)",
-                    kept * 2.0 * rows * conv_front_macs(c["L"], d["F"])))
+                    kept * 2.0 * rows * conv_front_macs(c["L"], d["F"]), None))
     return out
 
 
@@ -352,13 +373,23 @@ def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roo
 
     ndir = 2 if both else 1
     useful = glob * c["N"] * steps
+    fused, active_cols = False, False
+    if c["kind"] == "gauge":
+        plan = state["dyn"]._plan()
+        fused = (not layered) and Lh.l2hmc_gauge_plan_fused(C.byref(plan)) == 1
+        # both directions: rows [0, B) forward, [B, 2B) backward; selected-only rows carry per-row directions
+        # (no split known per tile: every column is formed)
+        active_cols = (not fused) and both and heads_use_active_columns(2 * B, dims["D"], dims["H"], B)
+    ex = 2.0 * executed_macs_per_lf(cfg, fused, active_cols)          # FLOPs per chain-LF step the kernels execute
+    per_s = ndir * glob * c["N"] / (dt / steps) / 1e12 / job.world    # executed chain-LF steps per second per GPU / 1e12
     res = {"cfg": cfg, "workload": c["name"], "value": useful / dt, "ms_per_step": 1e3 * dt / steps,
            "steps": steps, "warmup": warmup, "prewarm_steps_untimed": prewarm, "scaling": scaling,
            "global_batch": glob, "chains_this_rank": [lo, hi], "num_steps": c["N"], "eps": c["eps"],
            "directions_integrated": ndir, "executed_chain_lf_per_step": ndir * glob * c["N"],
-           "algorithmic_flops_per_chain_lf": 8 * macs,
-           "whole_step_tflops": ndir * glob * c["N"] * 8 * macs / (dt / steps) / 1e12 / job.world}
-    res["whole_step_frac"] = res["whole_step_tflops"] / PEAK_F32_MFMA_TFLOPS
+           "algorithmic_flops_per_chain_lf": 8 * macs, "executed_flops_per_chain_lf": ex,
+           "whole_step_tflops": per_s * ex, "whole_step_frac": per_s * ex / PEAK_F32_MFMA_TFLOPS,
+           "reference_flops_equiv_tflops": per_s * 8 * macs,
+           "reference_flops_equiv_frac": per_s * 8 * macs / PEAK_F32_MFMA_TFLOPS}
     if c["kind"] == "gauge":
         res["lattice"], res["beta"] = [c["L"], c["L"]], c["beta"]
         res["mean_accept_prob"] = stats.mean_accept()
@@ -370,21 +401,12 @@ def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roo
         rows = ndir * B
         if c["kind"] == "toy":
             classes = [(7, "small_traj_mfma_kernel (one launch per propose: Philox draws, both trajectories, mix, MH)",
-                        8.0 * macs * 2 * B * c["N"])]
+                        8.0 * macs * 2 * B * c["N"], None)]
         else:
-            from l2hmc_amd import _lib as _l
-            plan = state["dyn"]._plan()
-            fused = (not layered) and _l.lib().l2hmc_gauge_plan_fused(C.byref(plan)) == 1
-            # (csrc/stq_dense.hip: launch_heads needs the forward / backward split on a row-tile edge)
-            active_cols = (not fused) and both and B % 128 == 0
             classes = gauge_kernel_classes(cfg, rows, fused, active_cols)
-            ex = 2.0 * executed_macs_per_lf(cfg, fused, active_cols)
-            res["executed_flops_per_chain_lf"] = ex
-            res["whole_step_executed_tflops"] = ndir * glob * c["N"] * ex / (dt / steps) / 1e12 / job.world
-            res["whole_step_executed_frac"] = res["whole_step_executed_tflops"] / PEAK_F32_MFMA_TFLOPS
         nprof = max(1, min(steps, 20))
         per = []
-        for cls, name, flops in classes:
+        for cls, name, flops, ref_flops in classes:
             def run():
                 xs = x
                 for _ in range(nprof):
@@ -393,18 +415,26 @@ def run_workload(job, cfg, scaling, steps, warmup, both=True, layered=False, roo
             if n:
                 per.append(dict(kernel=name, launches=n, avg_us=us, flops_per_launch=flops,
                                 tflops=flops / (us * 1e-6) / 1e12, frac=flops / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS))
+                if ref_flops is not None:
+                    per[-1].update(reference_flops_per_launch=ref_flops,
+                                   reference_flops_equiv_frac=ref_flops / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS)
         if stats is not None:
             stats.wait()
         if per:
             dom = max(per, key=lambda d: d["avg_us"] * d["launches"])
             res["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"],
-                               "avg_launch_us": dom["avg_us"], "algorithmic_flops_per_launch": dom["flops_per_launch"],
+                               "avg_launch_us": dom["avg_us"], "executed_flops_per_launch": dom["flops_per_launch"],
+                               "flops_counted": "the FLOPs the kernel executes (recurring first-layer products kept, "
+                                                "masked head columns skipped); the reference graph's count is under "
+                                                "reference_flops_equiv_*",
                                "all_kernels": per, "whole_step_tflops": res["whole_step_tflops"],
-                               "whole_step_frac": res["whole_step_frac"]}
-            if "whole_step_executed_frac" in res:
-                res["roofline"]["whole_step_executed_tflops"] = res["whole_step_executed_tflops"]
-                res["roofline"]["whole_step_executed_frac"] = res["whole_step_executed_frac"]
+                               "whole_step_frac": res["whole_step_frac"],
+                               "reference_flops_equiv_tflops": res["reference_flops_equiv_tflops"],
+                               "reference_flops_equiv_frac": res["reference_flops_equiv_frac"]}
+            if "reference_flops_per_launch" in dom:
+                res["roofline"]["reference_flops_per_launch"] = dom["reference_flops_per_launch"]
+                res["roofline"]["kernel_reference_flops_equiv_frac"] = dom["reference_flops_equiv_frac"]
     return res, state
 
 
@@ -534,6 +564,7 @@ def main():
                    "directions_integrated": res["directions_integrated"],
                    "executed_chain_lf_per_step": res["executed_chain_lf_per_step"],
                    "algorithmic_flops_per_chain_lf": res["algorithmic_flops_per_chain_lf"],
+                   "executed_flops_per_chain_lf": res["executed_flops_per_chain_lf"],
                    "parallelism": f"chains sharded over {world} GPU(s) ({scaling} scaling), weights replicated"},
     }
     for k in ("lattice", "beta", "mean_accept_prob"):
@@ -571,11 +602,14 @@ def main():
                     xs = step(xs)
             us, n = profile_class(Lh, 5, run, _lib)
             stats.wait()
+            ex_lf, ref_lf = 2.0 * executed_macs_per_lf(3, True, False), 8.0 * net_macs(D, Hd)
             if n:
-                flops = 8.0 * net_macs(D, Hd) * rows * n_lf
-                tf = flops / (us * 1e-6) / 1e12
-                out["roofline"].update(achieved=tf, frac=tf / PEAK_F32_MFMA_TFLOPS, avg_launch_us=us)
-                out["roofline"]["all_kernels"][0].update(avg_us=us, launches=n, tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS)
+                tf = ex_lf * rows * n_lf / (us * 1e-6) / 1e12
+                rtf = ref_lf * rows * n_lf / (us * 1e-6) / 1e12
+                out["roofline"].update(achieved=tf, frac=tf / PEAK_F32_MFMA_TFLOPS, avg_launch_us=us,
+                                       kernel_reference_flops_equiv_frac=rtf / PEAK_F32_MFMA_TFLOPS)
+                out["roofline"]["all_kernels"][0].update(avg_us=us, launches=n, tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
+                                                         reference_flops_equiv_frac=rtf / PEAK_F32_MFMA_TFLOPS)
             # The step kernel also draws the momenta and finishes the step (mix, MH, observables, wrap).  The same
             # kernel launched for the trajectories alone (l2hmc_gauge_trajectory: same rows, same FLOPs, no step
             # prologue / epilogue) separates the integrator's MFMA efficiency from that fixed per-step work.
@@ -586,11 +620,12 @@ def main():
             us, n = profile_class(Lh, 5, lambda: [dyn.transition_kernel(x2, beta, forward=True, momentum=v2)
                                                   for _ in range(20)], _lib)
             if n:
-                tf = 8.0 * net_macs(D, Hd) * x2.shape[0] * n_lf / (us * 1e-6) / 1e12
+                tf = ex_lf * x2.shape[0] * n_lf / (us * 1e-6) / 1e12
                 out["roofline"]["trajectory_only"] = {
                     "what": "the same kernel launched for the two trajectories alone (l2hmc_gauge_trajectory, "
                             f"{x2.shape[0]} rows x {n_lf} LF): no draws, no mix / MH / observables / wrap",
-                    "avg_launch_us": us, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS}
+                    "avg_launch_us": us, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                    "reference_flops_equiv_frac": tf * ref_lf / ex_lf / PEAK_F32_MFMA_TFLOPS}
             # fabric-side bytes per launch of the fused kernel at this exact shape: read from the newest committed
             # PMC summary (tools/pmc_collect.sh + tools/pmc_summary.py -> profiles/rNN_pmc_fused_kernel.json);
             # null if no summary is committed or the shape differs -- never a literal
@@ -650,12 +685,14 @@ def main():
                     xb = bsmp.step(xb, beta)[0]
                 torch.cuda.synchronize()
                 tbd = (time.perf_counter() - tb0) / 20
-                fl2 = 8.0 * net_macs(2 * c["L"] ** 2, 8 * c["L"] ** 2) * (2 * B2) * n_lf
+                fl2 = 2.0 * executed_macs_per_lf(3, True, False) * (2 * B2) * n_lf           # executed
+                ref2 = 8.0 * net_macs(2 * c["L"] ** 2, 8 * c["L"] ** 2) * (2 * B2) * n_lf     # the reference graph's count
                 out["config"]["twice_the_chains"] = {
                     "what": f"{B2} chains on one GPU, same dynamics: gauge_traj_fused32_kernel (32 rows per workgroup), "
                             "results bit-identical to the 16-row form",
                     "ms_per_step": 1e3 * tbd, "chain_leapfrog_steps_per_s": B2 * n_lf / tbd,
-                    "whole_step_tflops": fl2 / tbd / 1e12, "whole_step_frac": fl2 / tbd / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                    "whole_step_tflops": fl2 / tbd / 1e12, "whole_step_frac": fl2 / tbd / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "reference_flops_equiv_frac": ref2 / tbd / 1e12 / PEAK_F32_MFMA_TFLOPS}
                 bsmp.stats.wait()
 
                 def run2():
@@ -667,11 +704,89 @@ def main():
                 if n2:
                     out["config"]["twice_the_chains"].update(
                         kernel_avg_us=us2, kernel_launches=n2, kernel_tflops=fl2 / (us2 * 1e-6) / 1e12,
-                        kernel_frac=fl2 / (us2 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                        kernel_frac=fl2 / (us2 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        kernel_reference_flops_equiv_frac=ref2 / (us2 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS)
                 del bdyn, bsmp, xb
             except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
                 out["config"]["twice_the_chains"] = {"error": repr(e)}
                 failed.append("twice_the_chains")
+
+        # ---- secondary: the same chains with only the direction each chain's coin selects integrated.  Bit-identical
+        #      chains (tests), but it SKIPS half of the work the reference does: evidence, never the headline ----
+        if rank == 0 and world == 1 and not args.no_roofline and both and not args.layered:
+            try:
+                sdyn = build_gauge(3, BATCH, both_directions=False)
+                sdyn.set_masks(dyn.mask.cpu().numpy())
+                ssmp = GaugeSampler(sdyn)
+                xs_ = x.clone()
+                for _ in range(10):
+                    xs_ = ssmp.step(xs_, beta)[0]
+                torch.cuda.synchronize()
+                ts0 = time.perf_counter()
+                for _ in range(20):
+                    xs_ = ssmp.step(xs_, beta)[0]
+                torch.cuda.synchronize()
+                tsd = (time.perf_counter() - ts0) / 20
+                ssmp.stats.wait()
+                ex1 = 2.0 * executed_macs_per_lf(3, True, False) * BATCH * n_lf
+                out["config"]["selected_only"] = {
+                    "what": f"{BATCH} chains, L2HMC_PLAN_SELECTED_ONLY: each chain integrated only in the direction its "
+                            "coin picks (same Philox streams, bit-identical chains whenever the other direction is finite)",
+                    "skips": "unselected direction (half of the reference's work per step)",
+                    "ms_per_step": 1e3 * tsd, "chain_leapfrog_steps_per_s": BATCH * n_lf / tsd,
+                    "whole_step_tflops": ex1 / tsd / 1e12, "whole_step_frac": ex1 / tsd / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                del sdyn, ssmp, xs_
+            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
+                out["config"]["selected_only"] = {"error": repr(e)}
+                failed.append("selected_only")
+
+        # ---- secondary: what the per-step collective costs on this one GPU.  A one-rank RCCL group is created and the
+        #      sampler issues its fused 12-byte all-reduce on the side stream after every step, exactly as at N > 1
+        #      (l2hmc_amd/dist.py); timed plain / with RCCL / plain again on the same clocks ----
+        if rank == 0 and world == 1 and dist is None and not args.no_roofline and not args.layered:
+            try:
+                import torch.distributed as tdist
+                with socket.socket() as sck:
+                    sck.bind(("127.0.0.1", 0))
+                    port = sck.getsockname()[1]
+                tdist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         device_id=dev)
+                os.environ["L2HMC_COLLECTIVES_AT_WORLD1"] = "1"
+                try:
+                    rsmp = GaugeSampler(dyn, dist=tdist)
+                finally:
+                    del os.environ["L2HMC_COLLECTIVES_AT_WORLD1"]
+                assert rsmp.stats.dist is not None
+
+                def timed(smp, n):
+                    xs_ = x
+                    for _ in range(20):
+                        xs_ = smp.step(xs_, beta)[0]
+                    smp.stats.wait()
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    for _ in range(n):
+                        xs_ = smp.step(xs_, beta)[0]
+                    smp.stats.join()
+                    torch.cuda.synchronize()
+                    d_ = (time.perf_counter() - t0_) / n
+                    smp.stats.wait()
+                    return d_
+                nw = max(steps, 50)
+                plain_a, with_rccl, plain_b = timed(sampler, nw), timed(rsmp, nw), timed(sampler, nw)
+                plain = 0.5 * (plain_a + plain_b)
+                out["config"]["world1_rccl"] = {
+                    "what": "the headline step with a one-rank RCCL group: one fused all_reduce(SUM) of [sum p, sum |dQ|, n] "
+                            "per MCMC step on a side stream (the collective of N > 1, gauge_model.py:795), same GPU, same "
+                            f"clocks, {nw} steps each: plain, with RCCL, plain",
+                    "ms_per_step_plain": [1e3 * plain_a, 1e3 * plain_b], "ms_per_step_with_rccl": 1e3 * with_rccl,
+                    "collective_cost_ms_per_step": 1e3 * (with_rccl - plain),
+                    "collective_cost_frac_of_step": (with_rccl - plain) / plain}
+                del rsmp
+                tdist.destroy_process_group()
+            except Exception as e:                 # noqa: BLE001 -- reported in the JSON line, exit code non-zero
+                out["config"]["world1_rccl"] = {"error": repr(e)}
+                failed.append("world1_rccl")
 
         # ---- secondary: one training step (loss + gradients + all-reduce + Adam) on the same shape; every rank
         #      takes part because the gradient bucket is all-reduced (f1/f2) ----
@@ -744,13 +859,18 @@ def main():
     # ---- CPU baseline: op-for-op torch-CPU port of the reference graph, bounded sample, rank 0 at N = 1 ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_for(cfg, st)
+        # BASELINE.md publishes no number for this metric (the reference has no benchmark): the only baseline that can
+        # exist here is the one timed beside it, so the ratio is against THAT and labelled as such
+        out["vs_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["vs_baseline_what"] = (f"value / cpu_baseline.value: the torch-CPU op-for-op port of the reference graph on "
+                                   f"{out['cpu_baseline']['cores']} host threads of this box (north_star target >= 50x at "
+                                   "1 GPU); BASELINE.md holds no published number for this metric")
 
     # ---- the other BASELINE configs at their per-GPU size (N = 1, default line only): compact table ----
     if cfg == 3 and world == 1 and not args.no_configs_table and not args.layered and both:
         table = [{"cfg": 3, "workload": c["name"], "chains": st["B"], "ms_per_step": out["ms_per_step"],
-                  "value": out["value"], "tflops": out.get("roofline", {}).get("whole_step_tflops"),
-                  "frac": out.get("roofline", {}).get("whole_step_frac"),
-                  "executed_frac": out.get("roofline", {}).get("whole_step_executed_frac"),
+                  "value": out["value"], "tflops": res["whole_step_tflops"], "frac": res["whole_step_frac"],
+                  "reference_flops_equiv_frac": res["reference_flops_equiv_frac"],
                   "kernel": out.get("roofline", {}).get("kernel"),
                   "kernel_avg_us": out.get("roofline", {}).get("avg_launch_us"),
                   "kernel_frac": out.get("roofline", {}).get("frac")}]
@@ -762,7 +882,7 @@ def main():
                 rf = r.get("roofline", {})
                 table.append({"cfg": oc, "workload": r["workload"], "chains": s2["B"], "ms_per_step": r["ms_per_step"],
                               "value": r["value"], "tflops": r["whole_step_tflops"], "frac": r["whole_step_frac"],
-                              "executed_frac": r.get("whole_step_executed_frac"),
+                              "reference_flops_equiv_frac": r["reference_flops_equiv_frac"],
                               "kernel": rf.get("kernel"), "kernel_avg_us": rf.get("avg_launch_us"),
                               "kernel_frac": rf.get("frac"),
                               "kernels": [{"kernel": q["kernel"].split(" ")[0], "avg_us": q["avg_us"], "frac": q["frac"],
@@ -778,10 +898,11 @@ def main():
         out["configs"] = table
         out["configs_note"] = ("every BASELINE.json config on ONE GPU at its per-GPU size (configs 4 and 5: the 1/8 "
                                "shard of the 8-GPU partition, 1024 and 2048 chains); value = useful chain-LF/s, "
-                               "tflops / frac = the reference's FLOPs of the whole step (every first layer and every "
-                               "head column formed anew) per second against the fp32 MFMA peak, executed_frac = the "
-                               "FLOPs the kernels actually execute (kept first-layer products, position sub-updates on "
-                               "the columns they move); `python bench.py --config c [--gpus N]` runs one of them as the headline")
+                               "tflops / frac = the FLOPs the kernels EXECUTE over the whole step (kept first-layer "
+                               "products, position sub-updates on the columns they move) per second against the fp32 "
+                               "MFMA peak, reference_flops_equiv_frac = the reference graph's count (every first layer "
+                               "and every head column formed anew) over the same time -- work equivalent, not "
+                               "utilisation; `python bench.py --config c [--gpus N]` runs one of them as the headline")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -51,10 +51,31 @@ __device__ __forceinline__ void mfma_block(const f32x4 a, const f32x4 (&b)[NT], 
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][e], a[e], acc[t], 0, 0, 0);
 }
 
+// A lane's 16 bytes of a 1 KiB weight fragment, as a BUFFER load: the wave's section base sits in a scalar buffer
+// resource, the fragment's byte offset in a scalar register, and the lane supplies ONE 32-bit offset
+// (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen).  With a 64-bit per-lane address instead (global_load with two
+// address registers per lane -- what the compiler makes of pointer arithmetic, even on a provably uniform base) every
+// load costs the matrix pipe ~3 cycles per MFMA more: 37.5 against 34.8 cycles per v_mfma_f32_16x16x4_f32 in
+// tools/mfma_pinned_bench.hip (profiles/r04_mfma_pinned_bench.txt) -- this, more than the load's placement, is the
+// "issue cost" rounds 2-3 measured.  Reads beyond the resource's size return 0 (never a fault).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+struct WSection {
+  __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ WSection wsection(const float* __restrict__ base) {
+  // raw buffer, stride 0, 2 GiB window (the images are a few MB; 151 MB at most in the layered path, not used there)
+  return {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)};
+}
+__device__ __forceinline__ f32x4 lane_frag(const WSection& ws, unsigned frag_index) {
+  const unsigned off = (threadIdx.x & 63u) * 16u;
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, off, frag_index * 1024u, 0));
+}
+
+// wp (below): the WAVE's section base, wave-uniform (kernel argument + readfirstlane'd wave number)
 template <int NT>
-__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const float* __restrict__ wp, int kc) {
+__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const WSection& ws, int kc) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
+  for (int t = 0; t < NT; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NT + t));
 }
 
 // Ring of B fragments, DEPTH slots of NT fragments; chunk k of the walk lives in slot k % DEPTH and every slot is
@@ -76,9 +97,9 @@ struct BRing {
 };
 
 template <int NT, int T0, int T1>
-__device__ __forceinline__ void load_group(f32x4 (&b)[NT], const float* __restrict__ wp, int kc) {
+__device__ __forceinline__ void load_group(f32x4 (&b)[NT], const WSection& ws, int kc) {
 #pragma unroll
-  for (int t = T0; t < T1; ++t) b[t] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + t) * 256);
+  for (int t = T0; t < T1; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NT + t));
 }
 
 // rev: the layer's k-chunks are walked from the last to the first (NKC chunks in all).  A network's image is
@@ -88,9 +109,10 @@ __device__ __forceinline__ void load_group(f32x4 (&b)[NT], const float* __restri
 template <int NT, int DEPTH>
 __device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp, bool rev = false,
                                            int nkc = 0) {
+  const WSection ws = wsection(wp);
 #pragma unroll
-  for (int s = 0; s < DEPTH - 1; ++s) load_frags<NT>(R.b[s], wp, rev ? nkc - 1 - s : s);
-  load_group<NT, 0, (NT + 1) / 2>(R.b[DEPTH - 1], wp, rev ? nkc - DEPTH : DEPTH - 1);
+  for (int s = 0; s < DEPTH - 1; ++s) load_frags<NT>(R.b[s], ws, rev ? nkc - 1 - s : s);
+  load_group<NT, 0, (NT + 1) / 2>(R.b[DEPTH - 1], ws, rev ? nkc - DEPTH : DEPTH - 1);
 }
 
 // Half a block: acc[t] += cur[t] (x) a over the chunk's four k-steps for the tiles [T0, T1), e-major (every
@@ -107,10 +129,31 @@ __device__ __forceinline__ void sched_mfma_load_pipeline() {
   }
 }
 
-template <int NT, int T0, int T1, int L0, int L1, bool LOAD>
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0>
 __device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
-                                                 f32x4 (&acc)[NT], const float* __restrict__ wp, int kc) {
+                                                 f32x4 (&acc)[NT], const WSection& wp, int kc) {
   constexpr int G = T1 - T0, NLD = L1 - L0;
+#ifdef L2HMC_MFMA_ASM
+  // experiment: accumulate IN PLACE (vDst == SrcC) through inline asm, order pinned by sched_barrier
+#pragma unroll
+  for (int i = 0; i < 4 * G; ++i) {
+    const int e = i / G, t = T0 + i % G;
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(cur[t][e]), "v"(a[e]));
+    if ((i & 3) == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LOAD) {
+        if ((i >> 2) < NLD)
+          dst[L0 + (i >> 2)] = lane_frag(wp, (unsigned)(kc * NT + L0 + (i >> 2)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (LOAD) {
+#pragma unroll
+    for (int j = G; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
+  }
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 4 * G; ++i) {
     const int e = i / G, t = T0 + i % G;
@@ -118,22 +161,29 @@ __device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cu
   }
   if constexpr (LOAD) {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) dst[L0 + j] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + L0 + j) * 256);
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
   }
-  // the order the scheduler must emit: four MFMAs, one load, four MFMAs, one load, ...
+  // the order the scheduler must emit: the NDS LDS reads of the NEXT block's activation fragment first (left to float
+  // they sink to the block's end and the next block waits out the whole LDS latency), then four MFMAs, one load, ...
+  if constexpr (NDS > 0) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
   sched_mfma_load_pipeline<G, LOAD ? NLD : 0>();
 }
 
-// wp: this wave's section base + lane * 4.  afrag(kc) returns the lane's A fragment of chunk kc
+// wp: this wave's section base (wave-uniform).  afrag(kc) returns the lane's A fragment of chunk kc
 // (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
 template <int NT, int NKC, int DEPTH, typename AF>
-__device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wp, AF afrag,
+__device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wbase, AF afrag,
                                              f32x4 (&acc)[NT], bool rev = false) {
+  const WSection wp = wsection(wbase);
   static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
   constexpr int G = (NT + 1) / 2;                              // tiles [0, G) and [G, NT)
   auto km = [&](int k) { return rev ? NKC - 1 - k : k; };      // position in the walk -> chunk
   // block k requests group 1 of chunk k + DEPTH - 1 (first half) and group 0 of chunk k + DEPTH (second half)
   constexpr int MAIN = (NKC - DEPTH) / DEPTH * DEPTH;          // rolled loop: both requests in range
+  // Nothing crosses this point: the pipeline below takes ANY vector-memory read of its scheduling region for its load
+  // slots -- without the fence it pulls the ring_prime loads a caller issued just above into them (first-layer
+  // halves), every MFMA group then waits for the load in front of it (vmcnt(0) per group: measured, 1.9 x slower).
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 a0 = afrag(km(0));
   int kc = 0;
 #pragma nounroll
@@ -141,7 +191,7 @@ __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* _
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
       const f32x4 a1 = afrag(km(kc + s + 1));
-      mfma_half_stream<NT, 0, G, G, NT, true>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(kc + s + DEPTH - 1));
+      mfma_half_stream<NT, 0, G, G, NT, true, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(kc + s + DEPTH - 1));
       mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(kc + s + DEPTH));
       a0 = a1;
     }
@@ -151,15 +201,16 @@ __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* _
     const int s = (k - MAIN) % DEPTH;
     const f32x4 a1 = afrag(km(k + 1 < NKC ? k + 1 : NKC - 1));
     if (k + DEPTH - 1 < NKC)
-      mfma_half_stream<NT, 0, G, G, NT, true>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(k + DEPTH - 1));
+      mfma_half_stream<NT, 0, G, G, NT, true, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(k + DEPTH - 1));
     else
-      mfma_half_stream<NT, 0, G, G, NT, false>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, 0);
+      mfma_half_stream<NT, 0, G, G, NT, false, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, 0);
     if (k + DEPTH < NKC)
       mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(k + DEPTH));
     else
       mfma_half_stream<NT, G, NT, 0, G, false>(a0, R.b[s], R.b[s], acc, wp, 0);
     a0 = a1;
   }
+  __builtin_amdgcn_sched_barrier(0);                           // ... and the next layer's priming loads stay behind it
 }
 
 }  // namespace l2hmc

@@ -329,9 +329,10 @@ __global__ __launch_bounds__(kFThreads) void gauge_train_bwd_fused_kernel(FusedB
       __syncthreads();
 
       // ================= phase B: delta2 = (dout . Whd) gated by h2 > 0
-      const float* wpb1 = pk + (size_t)wave * Cfg::KCO * NT1 * 256 + lane * 4;
-      const float* wpb2 = pk + Cfg::P1 + (size_t)wave * Cfg::KCH * NT1 * 256 + lane * 4;
-      const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KCH * NT3 * 256 + lane * 4;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);    // provably uniform: the weight loads' base stays in SGPRs
+      const float* wpb1 = pk + (size_t)wv * Cfg::KCO * NT1 * 256;
+      const float* wpb2 = pk + Cfg::P1 + (size_t)wv * Cfg::KCH * NT1 * 256;
+      const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wv * Cfg::KCH * NT3 * 256;
       BRing<NT1, 4> R2;
       {
         BRing<NT1, 4> R1;
@@ -635,9 +636,10 @@ __global__ __launch_bounds__(kFThreads) void gauge_trunk_bwd_kernel(TrunkBwdArgs
   __syncthreads();
 
   const float* pk = p.pk;
-  const float* wpb1 = pk + (size_t)wave * Cfg::KCO * NT1 * 256 + lane * 4;
-  const float* wpb2 = pk + Cfg::P1 + (size_t)wave * Cfg::KCH * NT1 * 256 + lane * 4;
-  const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KCH * NT3 * 256 + lane * 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);        // provably uniform: the weight loads' base stays in SGPRs
+  const float* wpb1 = pk + (size_t)wv * Cfg::KCO * NT1 * 256;
+  const float* wpb2 = pk + Cfg::P1 + (size_t)wv * Cfg::KCH * NT1 * 256;
+  const float* wpb3 = pk + Cfg::P1 + Cfg::P2 + (size_t)wv * Cfg::KCH * NT3 * 256;
   const bool rlive = r < nrow;
   const int64_t rrow = row0 + (rlive ? r : 0);    // lane (q, r): row r, four consecutive columns (fused_common.h)
   // ---- phase B: delta2 = (dout . Whd) gated by h2 > 0

@@ -471,9 +471,10 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
           tape_store(dst + (tcr0 + rr) * H + c4, *reinterpret_cast<const f32x4*>(src + rr * SH + c4));
       }
     };
-    const float* wp1 = pk + (size_t)wave * Cfg::KC1 * NT1 * 256 + lane * 4;
-    const float* wp2 = pk + Cfg::P1 + (size_t)wave * Cfg::KC2 * NT1 * 256 + lane * 4;
-    const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wave * Cfg::KC2 * 3 * NTH * 256 + lane * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: the weight loads' base stays in SGPRs
+    const float* wp1 = pk + (size_t)wv * Cfg::KC1 * NT1 * 256;
+    const float* wp2 = pk + Cfg::P1 + (size_t)wv * Cfg::KC2 * NT1 * 256;
+    const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wv * Cfg::KC2 * 3 * NTH * 256;
     constexpr int DP1 = 3, DP2 = 3, DPH = 4;      // ring depths (fused_common.h): first-layer halves, layer 2, heads
     BRing<NT1, DP2> R2;
     BRing<3 * NTH, DPH> R3;

@@ -35,9 +35,9 @@ constexpr int kLds32 = 3 * kR32 * kSX + kR32 * kSH + 2 * kNC + kR32 * kSP + 2 * 
 
 // Half a block for both row groups (fused_common.h: mfma_half_stream): every weight fragment cur[t] feeds two MFMAs,
 // so one load goes behind every EIGHTH MFMA.  e-major per accumulator, as the 16-row form.
-template <int NT, int T0, int T1, int L0, int L1, bool LOAD>
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0>
 __device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
-                                                  f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const float* __restrict__ wp, int kc) {
+                                                  f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const WSection& wp, int kc) {
   constexpr int G = T1 - T0, NLD = L1 - L0;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -48,21 +48,24 @@ __device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1
     }
   if constexpr (LOAD) {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) dst[L0 + j] = *reinterpret_cast<const f32x4*>(wp + ((size_t)kc * NT + L0 + j) * 256);
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
   }
+  if constexpr (NDS > 0) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);     // the next block's two A fragments first
   sched_mfma_load_pipeline<G, LOAD ? NLD : 0, 8>();
 }
 
 // stream_layer (fused_common.h) for two row groups; ap = the lane's fragment address in row group 0, gstride = floats
 // between the groups' rows
 template <int NT, int NKC, int DEPTH>
-__device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* __restrict__ wp, const float* ap,
+__device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* __restrict__ wbase, const float* ap,
                                               int gstride, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], bool rev = false) {
+  const WSection wp = wsection(wbase);
   static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
   constexpr int G = (NT + 1) / 2;
   auto km = [&](int k) { return rev ? NKC - 1 - k : k; };
   auto af = [&](int kc, int g) { return *reinterpret_cast<const f32x4*>(ap + g * gstride + kc * 16); };
   constexpr int MAIN = (NKC - DEPTH) / DEPTH * DEPTH;
+  __builtin_amdgcn_sched_barrier(0);                           // (fused_common.h: stream_layer)
   f32x4 a0 = af(km(0), 0), c0 = af(km(0), 1);
   int kc = 0;
 #pragma nounroll
@@ -71,7 +74,7 @@ __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* 
     for (int s = 0; s < DEPTH; ++s) {
       const int kn = km(kc + s + 1);
       const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
-      mfma_half_stream2<NT, 0, G, G, NT, true>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
+      mfma_half_stream2<NT, 0, G, G, NT, true, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
                                                km(kc + s + DEPTH - 1));
       mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(kc + s + DEPTH));
       a0 = a1;
@@ -84,9 +87,9 @@ __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* 
     const int kn = km(k + 1 < NKC ? k + 1 : NKC - 1);
     const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
     if (k + DEPTH - 1 < NKC)
-      mfma_half_stream2<NT, 0, G, G, NT, true>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, km(k + DEPTH - 1));
+      mfma_half_stream2<NT, 0, G, G, NT, true, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, km(k + DEPTH - 1));
     else
-      mfma_half_stream2<NT, 0, G, G, NT, false>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, 0);
+      mfma_half_stream2<NT, 0, G, G, NT, false, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, 0);
     if (k + DEPTH < NKC)
       mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(k + DEPTH));
     else
@@ -94,6 +97,7 @@ __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* 
     a0 = a1;
     c0 = c1;
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
@@ -265,9 +269,10 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
                         bool prep_next_mask, int l1, const float (&tcr)[kG32], const float (&tsr)[kG32], int callidx) {
     const float* pk = net.packed;
     const bool zig = (callidx & 1) != 0;   // layers 2 and 3 alternate their direction per call (fused_common.h)
-    const float* wp1 = pk + (size_t)wave * kKC1 * NT1 * 256 + lane * 4;
-    const float* wp2 = pk + kP1 + (size_t)wave * kKC2 * NT1 * 256 + lane * 4;
-    const float* wph = pk + kP1 + kP2 + (size_t)wave * kKC2 * 3 * NTH * 256 + lane * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: the weight loads' base stays in SGPRs
+    const float* wp1 = pk + (size_t)wv * kKC1 * NT1 * 256;
+    const float* wp2 = pk + kP1 + (size_t)wv * kKC2 * NT1 * 256;
+    const float* wph = pk + kP1 + kP2 + (size_t)wv * kKC2 * 3 * NTH * 256;
     constexpr int DP1 = 3, DP2 = 3, DPH = 4;
     BRing<NT1, DP2> R2;
     BRing<3 * NTH, DPH> R3;

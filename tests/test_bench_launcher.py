@@ -49,6 +49,33 @@ def test_algorithmic_flops_match_the_survey_sizes_table():
     assert 8 * bench.config_macs(5)[0] == 1208090624
 
 
+def test_executed_flops_never_exceed_the_reference_count():
+    """Every `frac` of the bench line prices EXECUTED FLOPs (a fraction above 1 was printed for
+    cfg 5 because the reference's count was divided by the time of kernels that skip part of it).  The executed count
+    is at most the reference graph's for every config and every kernel path, equals it for the toy kernels, and
+    reproduces the counter-calibrated MFMA count of the whole-step kernel (87,031,808 of 94,371,840 instructions
+    per launch at cfg 3: profiles/r02_pmc_fused_kernel.json)."""
+    for cfg in (1, 2, 3, 4, 5):
+        ref = 8 * bench.config_macs(cfg)[0]
+        for fused in (False, True):
+            for active in (False, True):
+                ex = 2.0 * bench.executed_macs_per_lf(cfg, fused, active)
+                assert 0 < ex <= ref, (cfg, fused, active, ex, ref)
+                if cfg in (1, 2):
+                    assert ex == ref
+    # cfg 3, whole-step kernel: MFMA work only (the 2 H time-term products per call run on the VALU)
+    H, D, N = 512, 128, 10
+    mfma_ref = 4 * (2 * D * H + H * H + 3 * H * D)
+    mfma_ex = bench.executed_macs_per_lf(3, True, False) - 4 * 2 * H
+    assert abs(mfma_ex / mfma_ref - 87031808 / 94371840) < 1e-6
+    # the library's choice of the active-column form, mirrored in bench.heads_use_active_columns
+    assert bench.heads_use_active_columns(2 * 1024, 512, 1024, 1024)          # cfg 4 shard: 64 x 32 tiles, split % 64 == 0
+    assert bench.heads_use_active_columns(2 * 2048, 2048, 8192, 2048)         # cfg 5 shard: 128 x 64 tiles, split % 128 == 0
+    assert not bench.heads_use_active_columns(2 * 37, 128, 512, 37)           # split inside a tile
+    assert bench.heads_use_active_columns(2 * 64, 128, 512, 64) and not bench.heads_use_active_columns(2 * 96, 128, 512, 96)
+    assert not bench.heads_use_active_columns(2 * 16448, 2048, 8192, 16448)   # 128-row tiles, split % 128 == 64
+
+
 def _run(args, extra_env=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(extra_env or {})

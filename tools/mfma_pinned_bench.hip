@@ -39,6 +39,15 @@ __device__ __forceinline__ void gload(f32x4& d, unsigned voff, const float* sbas
   }
 }
 
+__device__ __forceinline__ void gload64(f32x4& d, const float* vaddr, int imm) {
+  // 64-bit per-lane address (what the compiler emits for the shipped kernel's ordinary loads)
+  switch (imm) {
+#define C(I) case I: asm volatile("global_load_dwordx4 %0, %1, off offset:" #I : "=v"(d) : "v"(vaddr)); break;
+    C(-4096) C(-3072) C(-2048) C(-1024) C(0) C(1024) C(2048) C(3072)
+#undef C
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm(f32x4 (&b)[NT]) {
   asm volatile("s_waitcnt vmcnt(%8)"
@@ -94,6 +103,97 @@ __global__ __launch_bounds__(256) void bench7(const float* __restrict__ w, float
         const int nx = min(kc + s + D - 1, nkc - 1);
         wait_vm<(D - 2) * NT>(b[s]);
         block_pinned<true>(a0, b[s], b[(s + D - 1) % D], acc, voff, wbase + (size_t)nx * NT * 256);
+        a0 = a1;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int t = 0; t < NT; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  for (int d = 0; d < D; ++d) s += b[d][0][0] * 1e-30f;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+// mode 7 variants (bisecting what separates mode 7 from the shipped core): ADDR64 = per-lane 64-bit addresses instead
+// of SGPR base + 32-bit offset; GROUP4 = tiles in two groups of four (acc re-used after 4 MFMAs, the A operand kept
+// for 4 consecutive MFMAs) with the ring re-loaded in place half a block late, as csrc/fused_common.h does
+template <int D, bool ADDR64, bool GROUP4>
+__global__ __launch_bounds__(256) void bench7v(const float* __restrict__ w, float* out, int nkc, int iters,
+                                               unsigned long long* cyc) {
+  __shared__ __attribute__((aligned(16))) float lds[16 * 520];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 16 * 520; i += 256) lds[i] = 0.001f * (i % 97);
+  __syncthreads();
+  f32x4 acc[NT];
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  const float* wbase = w + (size_t)__builtin_amdgcn_readfirstlane(wave) * nkc * NT * 256 + 1024;
+  const unsigned voff = lane * 16;
+  const float* vbase = wbase + lane * 4;
+  const float* ap = lds + (lane & 15) * 520 + (lane >> 4) * 4;
+  f32x4 b[D][NT];
+  auto ld = [&](f32x4& d, int chunk, int tile) {
+    if (ADDR64) gload64(d, vbase + (size_t)chunk * NT * 256, tile * 1024 - 4096);
+    else gload(d, voff, wbase + (size_t)chunk * NT * 256, tile * 1024 - 4096);
+  };
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if (GROUP4) {
+#pragma unroll
+      for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ld(b[s][t], s, t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ld(b[D - 1][t], D - 1, t);
+    } else {
+#pragma unroll
+      for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ld(b[s][t], s, t);
+    }
+    f32x4 a0 = *(const f32x4*)(ap);
+#pragma nounroll
+    for (int kc = 0; kc + D <= nkc; kc += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const f32x4 a1 = *(const f32x4*)(ap + ((kc + s + 1) & 31) * 16);
+        if (GROUP4) {
+          // in flight behind this block's fragments: (D - 1) blocks' worth of loads minus the half just issued
+          wait_vm<(D - 1) * NT - 4>(b[s]);
+          const int n1 = min(kc + s + D - 1, nkc - 1), n2 = min(kc + s + D, nkc - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][t][e], a0[e], acc[t], 0, 0, 0);
+            SB();
+            ld(b[(s + D - 1) % D][4 + e], n1, 4 + e);
+            SB();
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int t = 4; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][t][e], a0[e], acc[t], 0, 0, 0);
+            SB();
+            ld(b[s][e], n2, e);
+            SB();
+          }
+        } else {
+          const int nx = min(kc + s + D - 1, nkc - 1);
+          wait_vm<(D - 2) * NT>(b[s]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+              for (int t = 4 * h; t < 4 * h + 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][t][e], a0[e], acc[t], 0, 0, 0);
+              SB();
+              ld(b[(s + D - 1) % D][e * 2 + h], nx, e * 2 + h);
+              SB();
+            }
+          }
+        }
         a0 = a1;
       }
     }
@@ -368,6 +468,19 @@ void run10(const char* name, const float* w, float* out, unsigned long long* cyc
   printf("        %s\n", check(out));
 }
 
+template <int D, bool ADDR64, bool GROUP4>
+void run7v(const char* name, const float* w, float* out, unsigned long long* cyc, int nkc, int iters) {
+  bench7v<D, ADDR64, GROUP4><<<256, 256>>>(w, out, nkc, 2, cyc);
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
+  bench7v<D, ADDR64, GROUP4><<<256, 256>>>(w, out, nkc, iters, cyc);
+  (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  report(name, cyc, nkc, iters, ms, nkc / D * D);
+  printf("        %s\n", check(out));
+}
+
 template <int D>
 void run7(const char* name, const float* w, float* out, unsigned long long* cyc, int nkc, int iters) {
   bench7<D><<<256, 256>>>(w, out, nkc, 2, cyc);
@@ -422,6 +535,9 @@ int main() {
       make_ref(w, out, nkc, iters);
       run10<3>("mode 10: pinned interleave, ORDINARY loads (compiler waits), ring of 3", w, out, cyc, nkc, iters);
       run10<4>("mode 10: pinned interleave, ORDINARY loads (compiler waits), ring of 4", w, out, cyc, nkc, iters);
+      run7v<3, true, false>("mode 7 + 64-bit per-lane addresses, ring of 3", w, out, cyc, nkc, iters);
+      run7v<3, false, true>("mode 7 + tile groups of 4, in-place reload half a block late, ring of 3", w, out, cyc, nkc, iters);
+      run7v<3, true, true>("mode 7 + both, ring of 3", w, out, cyc, nkc, iters);
       run7<3>("mode 7: pinned schedule, 1 asm load per 4 MFMAs, ring of 3, vmcnt(8)", w, out, cyc, nkc, iters);
       run7<4>("mode 7: pinned schedule, 1 asm load per 4 MFMAs, ring of 4, vmcnt(16)", w, out, cyc, nkc, iters);
       run7<6>("mode 7: pinned schedule, 1 asm load per 4 MFMAs, ring of 6, vmcnt(32)", w, out, cyc, nkc, iters);
