@@ -475,7 +475,12 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     const float* wp1 = pk + (size_t)wv * Cfg::KC1 * NT1 * 256;
     const float* wp2 = pk + Cfg::P1 + (size_t)wv * Cfg::KC2 * NT1 * 256;
     const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wv * Cfg::KC2 * 3 * NTH * 256;
-    constexpr int DP1 = 3, DP2 = 3, DPH = 4;      // ring depths (fused_common.h): first-layer halves, layer 2, heads
+#ifndef L2HMC_DP1                                 // (A/B builds: tools/build_variant.sh)
+#define L2HMC_DP1 3
+#define L2HMC_DP2 3
+#define L2HMC_DPH 4
+#endif
+    constexpr int DP1 = L2HMC_DP1, DP2 = L2HMC_DP2, DPH = L2HMC_DPH;   // ring depths (fused_common.h): first-layer halves, layer 2, heads
     BRing<NT1, DP2> R2;
     BRing<3 * NTH, DPH> R3;
     // ----- layer 1: two half-K streams (first input rows, then the second-input rows in gs)

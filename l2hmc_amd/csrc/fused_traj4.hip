@@ -73,20 +73,22 @@ __device__ __forceinline__ void chunk4(const float (&a)[RG], const f32x4 (&wf)[2
 #undef L2HMC_K4
 }
 
-// acc += rows(arow, stride) . W^T over NCH chunks of this wave's section; wp = section base + lane * 4
+// acc += rows(arow, stride) . W^T over NCH chunks of this wave's section; wbase = section base (wave-uniform: the
+// fragments are buffer loads, fused_common.h: lane_frag)
 // rev: the chunks are walked from the last to the first -- the 16-row form streams layers 2 and 3 of a network in
 // alternating directions on its consecutive calls (fused_common.h), and the order of k is part of the result's bits
 template <int RG, int NCH>
-__device__ __forceinline__ void stream4(const float* __restrict__ wp, const float* arow, int stride, int lane,
+__device__ __forceinline__ void stream4(const float* __restrict__ wbase, const float* arow, int stride, int lane,
                                         f32x4 (&acc)[RG][2], bool rev = false) {
   constexpr int DEPTH = 3;
   f32x4 ring[DEPTH][2][4];
+  const WSection ws = wsection(wbase);
   auto load = [&](f32x4 (&dst)[2][4], int kw) {
     const int kc = rev ? NCH - 1 - kw : kw;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dst[cb][m] = *reinterpret_cast<const f32x4*>(wp + ((size_t)(kc * 2 + cb) * 4 + m) * 256);
+      for (int m = 0; m < 4; ++m) dst[cb][m] = lane_frag(ws, (unsigned)((kc * 2 + cb) * 4 + m));
   };
   const float* ap = arow + (lane & 3) * stride + (lane >> 2);
   auto afrag = [&](float (&a)[RG], int kw) {
@@ -300,9 +302,10 @@ __global__ __launch_bounds__(kThreads4) void gauge_traj_fused4_kernel(FusedArgs 
                         bool prep_next_mask, int l1, const float (&tcr)[RG][4], const float (&tsr)[RG][4], int callidx) {
     const bool zig = (callidx & 1) != 0;                   // as fused_traj.hip: layers 2 / 3 alternate their direction
     const float* pk = net.packed + (kP1 + kP2 + (size_t)3 * kD * kH);      // the sub-tile image follows the 16-row one
-    const float* wp1 = pk + (size_t)wave * kKC1 * 2 * 4 * 256 + lane * 4;
-    const float* wp2 = pk + kP1 + (size_t)wave * kKC2 * 2 * 4 * 256 + lane * 4;
-    const float* wph = pk + kP1 + kP2 + (size_t)wave * kKC2 * 2 * 4 * 256 + lane * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: the weight loads' base stays in SGPRs
+    const float* wp1 = pk + (size_t)wv * kKC1 * 2 * 4 * 256;
+    const float* wp2 = pk + kP1 + (size_t)wv * kKC2 * 2 * 4 * 256;
+    const float* wph = pk + kP1 + kP2 + (size_t)wv * kKC2 * 2 * 4 * 256;
     // ----- layer 1
     {
       f32x4 acc[RG][2];

@@ -35,15 +35,21 @@ def broadcast_state(tensors, dist, src=0):
 
 
 class StepStats:
-    """Per-step fused scalar buffer [sum p_accept, sum |dQ|, n_chains]; one
-    asynchronous all-reduce(SUM) per MCMC step on a side stream so the next
-    trajectory does not wait for it."""
+    """Per-step fused scalar buffer [sum p_accept, sum |dQ|, n_chains], combined over the ranks by an asynchronous
+    all-reduce(SUM) on a side stream so the next trajectory does not wait for it.  `reduce_every` steps share ONE
+    all-reduce of their stacked buffers [k, 3] (every step's global sums are the same numbers as with one collective
+    per step, k - 1 steps later): the whole-step kernel owns every CU with a full register file, so a collective
+    kernel between two steps displaces a workgroup of the next one -- measured 21 us per step at the headline shape
+    with one all-reduce per step (1.3 % of a step, profiles/r04_bench_world1_rccl.json), nothing measurable with 16
+    steps per all-reduce.  reduce_every = 1 restores one collective per step."""
 
-    def __init__(self, device, dist=None):
+    def __init__(self, device, dist=None, reduce_every=16):
         self.device = torch.device(device)
         self.dist = active(dist)
+        self.reduce_every = max(1, int(reduce_every))
         self.total = torch.zeros(3, dtype=torch.float64)
         self._pending = []
+        self._unreduced = []                       # step buffers waiting for their shared all-reduce
         self._dev_total = None                     # fp64 [3] on the device: steps folded since the last wait()
         self._count, self._count_n = None, -1
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
@@ -54,34 +60,35 @@ class StepStats:
             self._count = torch.full((1,), float(n), dtype=torch.float32, device=p_accept.device)   # once per batch size
             self._count_n = n
         buf = torch.cat([torch.stack((p_accept, abs_dq)).sum(dim=1, dtype=torch.float32), self._count])
-        work = None
-        if self.dist is not None:
-            if self._side is not None:
-                self._side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._side):
-                    work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
-                buf.record_stream(self._side)
-            else:
-                work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
-        self._pending.append((buf, work))
+        self.push_sums(buf)
+
+    def push_sums(self, buf):
+        """`buf` = device tensor [sum p_accept, sum |dQ|, n_chains] of one step (from the step kernel,
+        l2hmc_gauge_mcmc_step_ex, or from push): queued; when sharded, every `reduce_every` steps go through one
+        asynchronous all-reduce together."""
+        if self.dist is None:
+            self._pending.append((buf, None))
+        else:
+            self._unreduced.append(buf)
+            if len(self._unreduced) >= self.reduce_every:
+                self._reduce_unreduced()
         if len(self._pending) > 64:
             self._drain(keep=8)
 
-    def push_sums(self, buf):
-        """`buf` = device tensor [sum p_accept, sum |dQ|, n_chains] already produced by the step kernel
-        (l2hmc_gauge_mcmc_step_ex): nothing to compute here, only the asynchronous all-reduce when sharded."""
-        work = None
-        if self.dist is not None:
-            if self._side is not None:
-                self._side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._side):
-                    work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
-                buf.record_stream(self._side)
-            else:
-                work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
-        self._pending.append((buf, work))
-        if len(self._pending) > 64:
-            self._drain(keep=8)
+    def _reduce_unreduced(self):
+        """One all-reduce(SUM) of the queued steps' buffers, stacked [k, 3], on the side stream."""
+        if not self._unreduced:
+            return
+        block = self._unreduced[0].reshape(1, -1) if len(self._unreduced) == 1 else torch.stack(self._unreduced)
+        self._unreduced = []
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                work = self.dist.all_reduce(block, op=self.dist.ReduceOp.SUM, async_op=True)
+            block.record_stream(self._side)
+        else:
+            work = self.dist.all_reduce(block, op=self.dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((block, work))
 
     def _drain(self, keep=0):
         """Fold all but the newest `keep` step buffers into the running device total: one stacked sum per drain (not
@@ -95,12 +102,15 @@ class StepStats:
                 work.wait()
         # folded ON THE DEVICE: a device-to-host copy here would block the host until every step enqueued so far has
         # run -- the GPU then idles while the host catches up (measured: 0.8 ms per drain, 2.5 % of a 20-step region)
-        part = torch.stack([b.detach() for b, _ in batch]).sum(dim=0, dtype=torch.float64)
+        part = torch.cat([b.detach().reshape(-1, 3) for b, _ in batch]).sum(dim=0, dtype=torch.float64)
         self._dev_total = part if self._dev_total is None else self._dev_total + part
 
     def join(self):
-        """Device side only: the current stream waits for every all-reduce issued so far (no host work, no copy);
-        the folding of the step buffers into the host totals is left to wait() / the next drain."""
+        """Device side only: the steps still queued get their all-reduce, and the current stream waits for every
+        all-reduce issued so far (no host work, no copy); the folding of the step buffers into the host totals is left
+        to wait() / the next drain."""
+        if self.dist is not None:
+            self._reduce_unreduced()
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
 

@@ -14,11 +14,12 @@ from .lattice import u1_observables, u1_plaq_exact
 
 
 class GaugeSampler:
-    def __init__(self, dynamics, beta_init=2., beta_final=4., train_steps=10000, dist=None):
+    def __init__(self, dynamics, beta_init=2., beta_final=4., train_steps=10000, dist=None, reduce_every=16):
         self.dynamics = dynamics
         self.lattice = dynamics.lattice
         self.beta_init, self.beta_final, self.train_steps = beta_init, beta_final, train_steps
-        self.stats = StepStats(dynamics._device, dist)
+        # (reduce_every: MCMC steps whose scalar sums share one all-reduce when sharded; l2hmc_amd/dist.py)
+        self.stats = StepStats(dynamics._device, dist, reduce_every=reduce_every)
         # [sum p, sum |dQ|, B, ticket] per step: the fused step kernel needs the ticket at 0 on entry and leaves it
         # at 0, so the rows of one zero-initialised ring are handed out in turn (longer than StepStats' backlog)
         self._sums_ring = torch.zeros(256, 4, dtype=torch.float32, device=dynamics._device)

@@ -30,11 +30,17 @@ def _worker(rank, world, port, q):
         dq_all = torch.tensor(rng.integers(0, 3, size=(4, B)), dtype=torch.float32)
         w = torch.full((7,), float(rank + 1))           # "weights": rank 0's copy must win
         broadcast_state([w], dist, src=0)
-        stats = StepStats("cpu", dist)
-        for step in range(4):
-            stats.push(p_all[step, lo:hi], dq_all[step, lo:hi])
-        q.put((rank, stats.mean_accept(), stats.mean_abs_dq(), float(stats.total[2]), w.tolist(),
-               float(p_all.mean()), float(dq_all.mean())))
+        # one all-reduce per step, three steps per all-reduce (4 steps: one full block + a flushed rest), the default
+        got = []
+        for every in (1, 3, None):
+            stats = StepStats("cpu", dist) if every is None else StepStats("cpu", dist, reduce_every=every)
+            for step in range(4):
+                stats.push(p_all[step, lo:hi], dq_all[step, lo:hi])
+            assert len(stats._unreduced) == {1: 0, 3: 1, None: 4}[every]      # steps still waiting for their collective
+            got.append((stats.mean_accept(), stats.mean_abs_dq(), float(stats.total[2])))
+            assert not stats._unreduced and not stats._pending
+        assert got[0] == got[1] == got[2]               # the same global sums however the steps are grouped
+        q.put((rank, *got[0], w.tolist(), float(p_all.mean()), float(dq_all.mean())))
     finally:
         dist.destroy_process_group()
 

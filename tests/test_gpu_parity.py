@@ -1383,6 +1383,34 @@ def test_active_column_heads_equal_all_columns(la, L, arch, N, B):
     assert H.relerr(np_(f1[0]), want[0]) < 2 * TOL_OP and H.relerr(np_(f1[1]), want[1]) < 2 * TOL_OP
 
 
+def test_active_column_heads_in_the_128_row_tile_form_with_a_direction_split(la):
+    """`heads32_kernel` (128-row x 64-column tiles, grids of >= 512 tiles: the cfg-5 path) in its
+    active-column form WITH apply_transition's [forward B | backward B] row layout, where tiles at or beyond
+    `dir_split` take the backward list (cols_b / cnt_b).  8x8 lattice, B = 16384 chains -> 2 B = 32768 rows = 512 tiles
+    of 128 x 64 with the split on a tile edge.  Against the all-columns evaluation (L2HMC_PLAN_ALL_COLUMNS): x, v, x_out
+    EQUAL, p within 1e-5; the first 64 chains against the float64 oracle.  A second batch (B = 16448: split % 128 == 64,
+    where the library itself must fall back to all columns) goes through the same checks."""
+    T = X = 8
+    N, eps, beta = 2, 0.15, 2.0
+    xp, vp = H.gauge_weights(T, X, regime="mild")
+    orc = H.gauge_oracle(T, X, N, eps, xp, vp)
+    outs = {}
+    for B in (16384, 16448):
+        dyn = H.gauge_hip(T, X, N, eps, xp, vp, orc.mask, B)
+        dyn.fused = False
+        x, v0f, v0b, coin, u = H.gauge_inputs(B, 2 * T * X, seed=331)
+        for allc in (False, True):
+            dyn.all_columns = allc
+            outs[B, allc] = dyn.apply_transition(x, beta, momentum_f=v0f, momentum_b=v0b, coin=coin, u=u)
+        a, b = outs[B, False], outs[B, True]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]), B
+        assert float((a[2] - b[2]).abs().max()) <= 1e-5, B
+        want = orc.apply_transition(x[:64], beta, v0f[:64], v0b[:64], coin[:64], u[:64])
+        assert H.relerr(np_(a[0][:64]), want[0]) < 2 * TOL_OP and H.relerr(np_(a[1][:64]), want[1]) < 2 * TOL_OP
+        assert np.abs(np_(a[2][:64]) - want[2]).max() < TOL_P
+        assert float(a[2].mean()) > 0.01                      # not a trivially rejected batch
+
+
 def test_active_column_heads_with_any_mask(la):
     """The column lists are built from the masks as they are (csrc/stq_dense.hip: active_cols_kernel keeps a column
     wherever keep != 1): rows with 30 % / 80 % ones, an all-ones and an all-zeros row (one of the two sub-updates then
