@@ -80,6 +80,27 @@ void prof_after(int cls, hipStream_t stream);
 // the VALU -- quad swaps, half-row and row mirrors, then the two row broadcasts that fold the four 16-lane rows into
 // lane 63 -- and one v_readlane: no LDS-crossbar traffic, where the __shfl_xor butterfly compiles to six dependent
 // ds_bpermute_b32 round trips (what kept the observable-producing stencil kernels at half the HBM rate).
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming loads next to MFMAs: BUFFER loads.  The section's base sits in a scalar buffer resource, a wave-uniform
+// byte offset in a scalar register, and the lane supplies ONE 32-bit offset
+// (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen).  With a 64-bit per-lane address instead (global_load with two
+// address registers per lane -- what the compiler makes of pointer arithmetic, even on a provably uniform base) every
+// load costs the matrix pipe ~3 cycles per v_mfma_f32_16x16x4_f32 more: 37.5 against 34.8 cycles per MFMA in
+// tools/mfma_pinned_bench.hip (profiles/r04_mfma_pinned_bench.txt) -- this, more than the load's placement, is the
+// "issue cost" rounds 2-3 measured.  Reads beyond the resource's 2 GiB window return 0 (never a fault); the lane and
+// scalar offsets must stay below 2^31 bytes (callers base the resource at their tile).
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+struct WSection {
+  __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ WSection wsection(const float* __restrict__ base) {
+  return {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)};   // raw, stride 0
+}
+__device__ __forceinline__ f32x4_t buf_load16(const WSection& ws, unsigned lane_off_bytes, unsigned uniform_off_bytes) {
+  return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, lane_off_bytes, uniform_off_bytes, 0));
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_take(float v) {          // lanes of rows outside ROW_MASK receive 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));

@@ -51,24 +51,9 @@ __device__ __forceinline__ void mfma_block(const f32x4 a, const f32x4 (&b)[NT], 
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t][e], a[e], acc[t], 0, 0, 0);
 }
 
-// A lane's 16 bytes of a 1 KiB weight fragment, as a BUFFER load: the wave's section base sits in a scalar buffer
-// resource, the fragment's byte offset in a scalar register, and the lane supplies ONE 32-bit offset
-// (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen).  With a 64-bit per-lane address instead (global_load with two
-// address registers per lane -- what the compiler makes of pointer arithmetic, even on a provably uniform base) every
-// load costs the matrix pipe ~3 cycles per MFMA more: 37.5 against 34.8 cycles per v_mfma_f32_16x16x4_f32 in
-// tools/mfma_pinned_bench.hip (profiles/r04_mfma_pinned_bench.txt) -- this, more than the load's placement, is the
-// "issue cost" rounds 2-3 measured.  Reads beyond the resource's size return 0 (never a fault).
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-struct WSection {
-  __amdgpu_buffer_rsrc_t rs;
-};
-__device__ __forceinline__ WSection wsection(const float* __restrict__ base) {
-  // raw buffer, stride 0, 2 GiB window (the images are a few MB; 151 MB at most in the layered path, not used there)
-  return {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)};
-}
+// (WSection / buf_load16: common.h)  A lane's 16 bytes of the 1 KiB weight fragment number `frag_index` of a section
 __device__ __forceinline__ f32x4 lane_frag(const WSection& ws, unsigned frag_index) {
-  const unsigned off = (threadIdx.x & 63u) * 16u;
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, off, frag_index * 1024u, 0));
+  return buf_load16(ws, (threadIdx.x & 63u) * 16u, frag_index * 1024u);
 }
 
 // wp (below): the WAVE's section base, wave-uniform (kernel argument + readfirstlane'd wave number)

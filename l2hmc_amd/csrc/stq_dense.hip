@@ -104,14 +104,30 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   // second input is multiplied in at store time.  (The earlier form -- loads under `if (k0 < K1) ... else ...` with
   // the mask multiply right behind them -- made the compiler drain the load queue between the four A loads of
   // every second-input tile: the first layer ran 15 % behind the same-shape hidden layer.)
+  // They are BUFFER loads (common.h: buf_load16): one scalar resource per source, based at this tile's first row, a
+  // scalar k offset, and ONE 32-bit offset per lane and chunk -- next to MFMAs a load with a 64-bit per-lane address
+  // costs the matrix pipe more.
   f32x4 ra[A_CH], rb[B_CH];
   [[maybe_unused]] f32x4 rm[A_CH];
   [[maybe_unused]] bool tile_masked = false;
-  int64_t a_grow[A_CH], b_grow[B_CH];
+  [[maybe_unused]] unsigned a_off1[A_CH], a_off2[A_CH], b_off[B_CH];      // bytes from the tile's base (launcher: < 2^31)
+  [[maybe_unused]] WSection rs_a1, rs_a2, rs_b;
+  if constexpr (!RAGGED) {
+    rs_a1 = wsection(p.A1 + m0 * p.lda1);
+    rs_a2 = wsection((KIND != 2 && p.A2) ? p.A2 + m0 * p.lda2 : p.A1 + m0 * p.lda1);
+    rs_b = wsection(p.Wt + (int64_t)n0 * p.K);
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) a_grow[i] = a_ok[i] ? m0 + a_row[i] : p.rows - 1;
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned lr = (unsigned)((a_ok[i] ? m0 + a_row[i] : p.rows - 1) - m0);     // clamped row, tile-local
+      a_off1[i] = (lr * (unsigned)p.lda1 + (unsigned)a_kc[i]) * 4u;
+      a_off2[i] = (lr * (unsigned)(KIND != 2 ? p.lda2 : p.lda1) + (unsigned)a_kc[i]) * 4u;
+    }
 #pragma unroll
-  for (int i = 0; i < B_CH; ++i) b_grow[i] = b_ok[i] ? n0 + b_row[i] : p.N - 1;
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned lc = (unsigned)((b_ok[i] ? n0 + b_row[i] : p.N - 1) - n0);
+      b_off[i] = (lc * (unsigned)p.K + (unsigned)b_kc[i]) * 4u;
+    }
+  }
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
     if constexpr (RAGGED) {
@@ -147,12 +163,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
       }
     } else {
       const bool second = KIND != 2 && k0 >= p.K1;            // uniform
-      const float* abase = second ? p.A2 : p.A1;
-      const int64_t lda = second ? p.lda2 : p.lda1;
       const int kk0 = second ? k0 - p.K1 : k0;
+      if (second) {
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i)
-        ra[i] = *reinterpret_cast<const f32x4*>(abase + a_grow[i] * lda + kk0 + a_kc[i]);
+        for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a2, a_off2[i], (unsigned)kk0 * 4u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a1, a_off1[i], (unsigned)kk0 * 4u);
+      }
       if constexpr (KIND == 1) {
         tile_masked = second && p.cmask_f != nullptr;
         if (tile_masked) {
@@ -162,8 +180,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
         }
       }
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i)
-        rb[i] = *reinterpret_cast<const f32x4*>(p.Wt + b_grow[i] * p.K + k0 + b_kc[i]);
+      for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_off[i], (unsigned)k0 * 4u);
     }
   };
   auto store_tile = [&](int buf) {
@@ -456,10 +473,31 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     const int wcol = cols ? cols[b_ok[i] ? n0 + nn : ncol - 1] : n0 + nn;
     b_src[i] = ((int64_t)hd * p.D + wcol) * p.K;
   }
+  // aligned shapes: the tile loads are buffer loads (common.h: buf_load16) -- A based at this tile's first row, the
+  // weights at their start (launcher: 3 D K floats < 2 GiB); a chunk outside the tile / the column list points its
+  // lane beyond the resource's window and reads 0, so every load is unconditional
+  [[maybe_unused]] WSection rs_a, rs_b;
+  [[maybe_unused]] unsigned a_boff[A_CH], b_boff[B_CH];
+  if constexpr (!RAGGED) {
+    rs_a = wsection(p.A + m0 * p.lda);
+    rs_b = wsection(p.Wt);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      a_boff[i] = a_ok[i] ? ((unsigned)a_row[i] * (unsigned)p.lda + (unsigned)a_kc[i]) * 4u : 0xfffffff0u;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) b_boff[i] = b_ok[i] ? ((unsigned)b_src[i] + (unsigned)b_kc[i]) * 4u : 0xfffffff0u;
+  }
 
   f32x4 ra[A_CH], rb[B_CH];
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
+    if constexpr (!RAGGED) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a, a_boff[i], (unsigned)k0 * 4u);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_boff[i], (unsigned)k0 * 4u);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -626,17 +664,19 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   if (n0 >= ncol) return;                  // (uniform; before any barrier)
 
   // unconditional, clamped tile loads (rows past the end repeat the last row: their products are never stored)
-  const float* a_src[A_CH];
+  // (buffer loads, common.h: buf_load16 -- A based at this tile's first row, the weights at their start)
+  const WSection rs_a = wsection(p.A + m0 * p.lda), rs_b = wsection(p.Wt);
+  unsigned a_src[A_CH];
   int a_off[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
     const int row = c / CPR, kc = (c % CPR) * 4;
     const int64_t g = (m0 + row) < p.rows ? m0 + row : p.rows - 1;
-    a_src[i] = p.A + g * p.lda + kc;
+    a_src[i] = ((unsigned)(g - m0) * (unsigned)p.lda + (unsigned)kc) * 4u;
     a_off[i] = row * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
-  const float* b_src[B_CH];
+  unsigned b_src[B_CH];
   int b_off[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
@@ -645,15 +685,15 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
     const int hd = row >> 6, nn = row & 63;
     const int cidx = (n0 + nn) < ncol ? n0 + nn : ncol - 1;
     const int col = cols ? cols[cidx] : cidx;
-    b_src[i] = p.Wt + ((int64_t)hd * p.D + col) * p.K + kc;
+    b_src[i] = (unsigned)((((int64_t)hd * p.D + col) * p.K + kc) * 4);
     b_off[i] = (BM + row) * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
   f32x4 ra[A_CH], rb[B_CH];
   auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
+    for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a, a_src[i], (unsigned)(kt * BK) * 4u);
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * BK);
+    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_src[i], (unsigned)(kt * BK) * 4u);
   };
   auto store_tile = [&](int buf) {
     float* st = lds + buf * STAGE;
@@ -782,6 +822,9 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
 #ifdef L2HMC_STAMPS
   a.stamps = (g_stamp_cls == ((a.K1 < a.K || a.wt0 != nullptr || a.cmask_f != nullptr) ? 1 : 2)) ? g_stamp_buf : nullptr;
 #endif
+  // the aligned tile loads are buffer loads with 32-bit byte offsets inside a tile of at most 128 rows
+  L2HMC_REQUIRE((int64_t)128 * hmax(hmax(a.lda1, a.lda2), a.K) * 4 < (int64_t)1 << 31,
+                "gemm: row stride %d too long for the tile loads", hmax(hmax(a.lda1, a.lda2), a.K));
   a.ntiles = (int)ceil_div(a.N, 128);
   // 128-row tiles once they still fill the chip (>= 2 tiles per CU), else 64-row tiles
   const int64_t t128 = ceil_div(a.rows, 128) * a.ntiles;
@@ -881,6 +924,9 @@ int launch_active_cols(const float* masks, int num_steps, int D, int* lists, int
 int launch_heads(HeadsArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.K > 0 && a.D > 0 && a.A && a.Wt, "heads: bad arguments");
   const bool ragged = a.K % BK != 0 || a.lda % 4 != 0 || !aligned16(a.A) || !aligned16(a.Wt);
+  // (the aligned tile loads are buffer loads with 32-bit byte offsets: from the weights' start, from a tile's first row)
+  L2HMC_REQUIRE(ragged || ((int64_t)3 * a.D * a.K * 4 < ((int64_t)1 << 31) && (int64_t)128 * a.lda * 4 < ((int64_t)1 << 31)),
+                "heads: D=%d K=%d lda=%d too large for the tile loads", a.D, a.K, a.lda);
   // the active-column form needs row tiles of ONE direction: the split between forward and backward rows on a tile edge
   auto split_ok = [&](int bm) { return a.dir_split >= a.rows || a.dir_split % bm == 0; };
   if (a.cols_f && (a.mode != kHeadsUpdateX || !a.cols_b || !a.cnt_f || !a.cnt_b)) a.cols_f = nullptr;
