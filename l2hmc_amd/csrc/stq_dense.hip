@@ -253,20 +253,34 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
     const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + half * 4;
     const float* bs = lds + cur * STAGE + BM * LDK + (wn * WN + r) * LDK + half * 4;
+    // the fragments of k-step group kq + 1 are read from LDS while group kq's MFMAs issue (two register sets): read
+    // and used in the same group -- what the loop did through round 3 -- every group of MFMAs waited out the LDS
+    // latency of the reads in front of it (ISA: four ds_read_b128, s_waitcnt lgkmcnt, eight MFMAs, ...)
+    f32x4 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK);
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
-      f32x4 af[MT], bf[NT];
+      const int cb = kq & 1, nb = cb ^ 1;
+      if (kq + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + kq * 8);
+        for (int i = 0; i < MT; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + (kq + 1) * 8);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + kq * 8);
+        for (int j = 0; j < NT; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + (kq + 1) * 8);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][e], bf[cb][j][e], acc[i][j], 0, 0, 0);
+      // pinned order (left alone the scheduler sinks the reads back in front of their use): next group's reads, then
+      // this group's MFMAs
+      if (kq + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
     }
     if constexpr (KIND == 1) {
       if (kt + 1 == kt_dump) acc_io(nullptr, p.acc_out);   // uniform; at most once
@@ -557,20 +571,30 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     // read 7)
     const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + q * 4;
     const float* bs = lds + cur * STAGE + BM * LDK + (wn * 16 + r) * LDK + q * 4;
+    // (fragments of group kh + 1 are read while group kh's MFMAs issue: gemm_relu_kernel)
+    f32x4 af[2][RG], bf[2][3];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) bf[0][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK);
 #pragma unroll
     for (int kh = 0; kh < BK / 16; ++kh) {
-      f32x4 af[RG], bf[3];
+      const int cb = kh & 1, nb = cb ^ 1;
+      if (kh + 1 < BK / 16) {
 #pragma unroll
-      for (int i = 0; i < RG; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + kh * 16);
+        for (int i = 0; i < RG; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + (kh + 1) * 16);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) bf[h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + kh * 16);
+        for (int h = 0; h < 3; ++h) bf[nb][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + (kh + 1) * 16);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
           for (int i = 0; i < RG; ++i)
-            acc[h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[h][e], acc[h][i], 0, 0, 0);
+            acc[h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb][i][e], bf[cb][h][e], acc[h][i], 0, 0, 0);
+      if (kh + 1 < BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, RG + 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12 * RG, 0);
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
@@ -722,6 +746,8 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
     const int sw = (r >> 2) & 3;
     const float* as = lds + cur * STAGE + (wm * 64 + r) * LDK;
     const float* bs = lds + cur * STAGE + (BM + wn * 32 + r) * LDK;
+    // (reading group kq + 1's fragments under group kq's MFMAs, as gemm_relu_kernel does, was measured here: the two
+    //  k-step groups of a 16-deep k-tile give it nothing to hide and the second register set costs: 2241 -> 2374 us at cfg 5)
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       const int slot = ((2 * kq + half) ^ sw) << 2;

@@ -424,14 +424,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
   const bool col_ok = gcol < (isq ? p.N : p.M);
   // (Loads two stages ahead of the products -- two register slots, loop unrolled by two -- were measured: 164 VGPRs,
   // two workgroups per CU instead of three, 295 -> 319 us per product.  One stage ahead it stays.)
+  // Buffer loads (common.h: buf_load16): a scalar resource re-based at the stage's first row, one 32-bit offset per
+  // lane and row (< 16 rows of ldg floats); a row past the end or a column group past the operand's width points its
+  // lane beyond the resource's window and reads 0, so the four loads of a stage are unconditional.
   f32x4 rg[4];
+  unsigned goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) goff[i] = ((unsigned)(4 * kg + i) * (unsigned)ldg + (unsigned)gcol) * 4u;
   auto load_stage = [&](int64_t rr) {
+    const WSection rs = wsection(gsrc + rr * ldg);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t gr = rr + 4 * kg + i;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (col_ok && gr < rend) a = *reinterpret_cast<const f32x4*>(gsrc + gr * ldg + gcol);
-      rg[i] = a;
+      const bool ok = col_ok && rr + 4 * kg + i < rend;
+      rg[i] = buf_load16(rs, ok ? goff[i] : 0xfffffff0u, 0u);
     }
   };
   auto store_stage = [&](int buf) {
