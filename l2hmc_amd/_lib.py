@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("L2HMC_LIB_PATH") or os.path.join(_HERE, "libl2hmc_hip
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "l2hmc_hip.h")
 
 c_float_p = C.c_void_p   # device pointers travel as integers
-MAX_MIX, MAX_SMALL_DIM = 8, 8
+MAX_MIX, MAX_SMALL_DIM, MAX_SMALL_NODES = 8, 8, 64
 PLAN_LAYERED, PLAN_CONV3D, PLAN_SELECTED_ONLY, PLAN_RECOMPUTE, PLAN_TILES16_ONLY, PLAN_ALL_COLUMNS = 1, 2, 4, 8, 16, 32
 GRAD_BUCKET_REST = 6
 BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)

@@ -1,6 +1,13 @@
-"""`Dynamics` with the reference's surface (l2hmc/utils/dynamics.py:34-319) for
-the toy targets (MoG / Gaussian), backed by l2hmc_small_trajectory: the whole
-trajectory of every chain runs in one HIP launch."""
+"""`Dynamics` with the reference's surface (l2hmc/utils/dynamics.py:34-319).
+
+Two paths behind it, chosen per instance (`Dynamics.layered`):
+  * one launch per trajectory (l2hmc_small_trajectory / l2hmc_small_propose): the packed toy targets of
+    l2hmc_amd.distributions (GMM / Gaussian, x_dim <= 8, <= 8 components) with `network`-style nets of at most 64
+    hidden units -- BASELINE configs 1 and 2;
+  * layer by layer, for everything else the reference's constructor accepts (:35-43: ANY `energy_function`, any x_dim,
+    `net_factory` of any `num_nodes`): per sub-update of utils/dynamics.py:120-225 one S/T/Q evaluation through
+    l2hmc_stq_dense (any width) and one l2hmc_lf_update_v / _x launch; the energy gradient comes from the packed target's
+    kernel or, for an arbitrary callable on torch tensors, from torch.autograd (the reference's tf.gradients, :241-242)."""
 import ctypes as C
 
 import numpy as np
@@ -20,15 +27,15 @@ class Dynamics(object):
         # quirk Q2: eps = exp(alpha), alpha = log(eps) (:51-60)
         self.alpha = torch.log(torch.tensor(float(eps), dtype=torch.float32))
         self.eps_trainable = eps_trainable
+        if not callable(energy_function):
+            raise TypeError("energy_function must be callable: x [B, x_dim] -> energies [B]")
         self._fn = energy_function
+        # packed toy target (l2hmc_amd.distributions) or None = an arbitrary callable on torch tensors
         self._target = getattr(energy_function, "target", None)
-        if self._target is None:
-            raise TypeError("Dynamics on the HIP path needs an energy function made by "
-                            "l2hmc_amd.distributions (GMM / Gaussian).get_energy_function(); arbitrary "
-                            "Python callables cannot run inside the fused trajectory kernel")
-        if self._target.dim != x_dim:
-            raise ValueError(f"x_dim={x_dim} but the target has dimension {self._target.dim}")
-        self._target.to(self._device)
+        if self._target is not None:
+            if self._target.dim != x_dim:
+                raise ValueError(f"x_dim={x_dim} but the target has dimension {self._target.dim}")
+            self._target.to(self._device)
         self.trajectory_length = int(trajectory_length)
         self.hmc = hmc
         self._init_mask()
@@ -39,6 +46,9 @@ class Dynamics(object):
             self.XNet = net_factory(x_dim, scope='XNet', factor=2.0)
             self.VNet = net_factory(x_dim, scope='VNet', factor=1.0)
         self._seed, self._draws = int(seed), 0
+        # the one-launch kernels hold x_dim <= 8 and 64 hidden units, and evaluate the packed targets only
+        wide = (not hmc) and int(getattr(self.XNet, "num_nodes", 0)) > _lib.MAX_SMALL_NODES
+        self.layered = self._target is None or int(x_dim) > _lib.MAX_SMALL_DIM or wide
 
     @property
     def eps(self):
@@ -81,16 +91,74 @@ class Dynamics(object):
 
     def energy(self, x, aux=None):
         """:227-236."""
+        if self._target is None:
+            return self._fn(_lib.as_dev(x, self._device).reshape(-1, self.x_dim)) / self._temp()
         return self._target.energy_grad(x, self._temp(), want_grad=False)[0]
 
     def hamiltonian(self, x, v, aux=None):
         return self.energy(x) + self.kinetic(v)
 
     def grad_energy(self, x, aux=None):
-        """:241-242 -- closed form of the reference's tf.gradients."""
+        """:241-242 -- closed form of the reference's tf.gradients for the packed targets, torch.autograd of the
+        caller's function otherwise."""
+        if self._target is None:
+            with torch.enable_grad():
+                xg = _lib.as_dev(x, self._device).reshape(-1, self.x_dim).detach().clone().requires_grad_(True)
+                e = self._fn(xg)
+                if e.shape != (xg.shape[0],):
+                    raise ValueError(f"energy_function must return one energy per row: got {tuple(e.shape)}")
+                (g,) = torch.autograd.grad(e.sum(), xg)
+            return (g / self._temp()).contiguous()
         return self._target.energy_grad(x, self._temp())[1]
 
+    # ---- layer-by-layer path (utils/dynamics.py:120-225 sub-update by sub-update) ------------------------------------
+    def _sub_v(self, x, v, t, d, logdet):
+        """:123-132 / :158-166 (d = 0), :175-185 / :213-223 (d = 1): half-kick with VNet([x, grad, t])."""
+        g = self.grad_energy(x)
+        S, T, Q = self.VNet([x, g, t])
+        out, ld = torch.empty_like(v), torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+        _lib.check(_lib.lib().l2hmc_lf_update_v(v.data_ptr(), g.data_ptr(), S.data_ptr(), T.data_ptr(), Q.data_ptr(),
+                                                float(self.eps), d, v.shape[0], self.x_dim, out.data_ptr(), ld.data_ptr(),
+                                                _lib.stream_ptr(self._device)))
+        logdet += ld
+        return out
+
+    def _sub_x(self, x, v, keep, t, d, logdet):
+        """:134-156 (d = 0), :187-211 (d = 1): XNet([v, keep * x, t]); the kept coordinates pass through."""
+        S, T, Q = self.XNet([v, keep * x, t])
+        out, ld = torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().l2hmc_lf_update_x(x.data_ptr(), v.data_ptr(), keep.data_ptr(), S.data_ptr(), T.data_ptr(),
+                                                Q.data_ptr(), float(self.eps), d, x.shape[0], self.x_dim, out.data_ptr(),
+                                                ld.data_ptr(), _lib.stream_ptr(self._device)))
+        logdet += ld
+        return out
+
+    def _layered_run(self, x, v, backward, log_jac):
+        """forward (:255-281) or backward (:283-310) through the public sub-update operators."""
+        x0, v0 = x, v
+        lj = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        N = self.trajectory_length
+        for i in range(N):
+            step = N - i - 1 if backward else i
+            t = self._format_time(step)
+            m, mb = self._get_mask(step)
+            if not backward:                                   # :120-170
+                v = self._sub_v(x, v, t, 0, lj)
+                x = self._sub_x(x, v, m, t, 0, lj)
+                x = self._sub_x(x, v, mb, t, 0, lj)
+                v = self._sub_v(x, v, t, 0, lj)
+            else:                                              # :172-225
+                v = self._sub_v(x, v, t, 1, lj)
+                x = self._sub_x(x, v, mb, t, 1, lj)
+                x = self._sub_x(x, v, m, t, 1, lj)
+                v = self._sub_v(x, v, t, 1, lj)
+        return (x, v, lj) if log_jac else (x, v, self.p_accept(x0, v0, x, v, lj))
+
     def _plan(self):
+        if self.layered:
+            raise NotImplementedError(
+                "this Dynamics runs layer by layer (arbitrary energy function, x_dim > 8 or more than 64 hidden units): "
+                "the one-launch kernels (l2hmc_small_*) and the one-launch training step do not hold it")
         p = _lib.SmallPlan(x_dim=self.x_dim, trajectory_length=self.trajectory_length, hmc=int(bool(self.hmc)),
                            eps=float(self.eps), first_layer_form=int(self.first_layer_form), masks=self.mask.data_ptr(),
                            target=self._target.struct(self._temp()), num_nodes=0)
@@ -109,6 +177,8 @@ class Dynamics(object):
     def _run(self, x, init_v, backward, log_jac):
         x = _lib.as_dev(x, self._device).reshape(-1, self.x_dim)
         v = _lib.as_dev(init_v, self._device) if init_v is not None else self._normal(tuple(x.shape))
+        if self.layered:
+            return self._layered_run(x, v, backward, log_jac)
         rows = x.shape[0]
         X, V = torch.empty_like(x), torch.empty_like(x)
         lj = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -127,6 +197,8 @@ class Dynamics(object):
         B = x.shape[0]
         vf = _lib.as_dev(init_v_forward, self._device) if init_v_forward is not None else self._normal(tuple(x.shape))
         vb = _lib.as_dev(init_v_backward, self._device) if init_v_backward is not None else self._normal(tuple(x.shape))
+        if self.layered:
+            return self._layered_run(x, vf, False, log_jac), self._layered_run(x, vb, True, log_jac)
         xx, vv = torch.cat([x, x]), torch.cat([vf, vb])
         dirs = torch.cat([torch.zeros(B, dtype=torch.int32, device=x.device),
                           torch.ones(B, dtype=torch.int32, device=x.device)])

@@ -395,11 +395,8 @@ class MLPNet(_DenseSTQ):
         self.scale_f = torch.zeros(1, D, dtype=torch.float32, device=dev)
         self._packed = None
         self._ws = _lib.Workspace()
-
-    def __call__(self, inputs):
-        raise NotImplementedError(
-            "MLPNet is evaluated inside l2hmc_small_trajectory (one fused kernel per trajectory); "
-            "its widths are below the MFMA path's 32-multiple requirement")
+    # (callable on [a, b, t(, aux)] through l2hmc_stq_dense like the other nets -- any width: the layer-by-layer path of
+    #  l2hmc_amd.dynamics.Dynamics; the one-launch toy kernels evaluate the same weights inside their trajectory)
 
 
 def network(x_dim, scope, factor, num_nodes=50, rng=None, device=None):

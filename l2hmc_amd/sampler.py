@@ -40,7 +40,8 @@ def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False,
     B = x.shape[0]
     if aux is not None:
         raise NotImplementedError("aux inputs are only used by the out-of-scope VAE scripts")
-    if init_v is None and init_v_backward is None and dir_bits is None and u is None and not log_jac:
+    if (init_v is None and init_v_backward is None and dir_bits is None and u is None and not log_jac
+            and not dynamics.layered):
         # every draw is the library's: ONE launch (direction bit, both momenta, both trajectories, mix, MH);
         # same Philox streams, same numbers as the piecewise path below
         x = x.reshape(-1, dynamics.x_dim).contiguous()

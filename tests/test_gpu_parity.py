@@ -513,8 +513,10 @@ def test_generic_dynamics_and_propose(la, name):
     # temperature divides the energy (utils/dynamics.py:227-236)
     dyn.temperature = 2.0
     assert H.relerr(np_(dyn.energy(x)), g["energy"] / 2.0) < 2e-5
+    # an arbitrary callable is accepted (utils/dynamics.py:35-43) and runs layer by layer; a non-callable is not
+    assert la.Dynamics(2, lambda x: x.sum(1), trajectory_length=3, eps=0.1, net_factory=la.network).layered
     with pytest.raises(TypeError):
-        la.Dynamics(2, lambda x: x.sum(1), trajectory_length=3, eps=0.1, net_factory=la.network)
+        la.Dynamics(2, 3.0, trajectory_length=3, eps=0.1, net_factory=la.network)
 
 
 @pytest.mark.parametrize("name,B", [("mog_cfg2", 4096), ("scg_cfg1", 61)])
@@ -556,6 +558,112 @@ def test_one_launch_propose_equals_the_piecewise_path_bit_for_bit(la, name, B):
     hm = la.Dynamics(2, tgt.get_energy_function(), trajectory_length=3, eps=0.1, hmc=True)
     hplan = hm._plan()
     assert L.l2hmc_small_propose(C.byref(hplan), x.data_ptr(), B, seed, d0, None, Lv3.data_ptr(), None, None, None) != 0
+
+
+@pytest.mark.parametrize("name", ["mog_cfg2", "scg_cfg1"])
+def test_layer_by_layer_generic_dynamics_equals_the_one_launch_kernels(la, name):
+    """`Dynamics.layered` (l2hmc_amd/dynamics.py: one S/T/Q evaluation through l2hmc_stq_dense and one
+    l2hmc_lf_update_v / _x per sub-update of utils/dynamics.py:120-225) is the path for everything the one-launch toy
+    kernels do not hold.  On the shapes both paths take -- the committed cfg-1 / cfg-2 fixtures -- it must reproduce
+    the fixtures (float64 oracle) at the same bars, and therefore the one-launch kernels."""
+    g, tgt, dyn = _small(la, name)
+    assert not dyn.layered
+    dyn.layered = True
+    x = g["x"]
+    Xf, Vf, pf = dyn.forward(x, init_v=g["v0f"])
+    Xb, Vb, pb = dyn.backward(x, init_v=g["v0b"])
+    for got, key in ((Xf, "Xf"), (Vf, "Vf"), (Xb, "Xb"), (Vb, "Vb")):
+        assert H.relerr(np_(got), g[key]) < TOL_OP, key
+    assert np.abs(np_(pf) - g["pf"]).max() < TOL_P and np.abs(np_(pb) - g["pb"]).max() < TOL_P
+    Lx, Lv, px, outs = la.propose(x, dyn, init_v=g["v0f"], do_mh_step=True, init_v_backward=g["v0b"],
+                                  dir_bits=g["dir_bits"], u=g["u"])
+    assert H.relerr(np_(Lx), g["Lx"]) < TOL_OP and H.relerr(np_(Lv), g["Lv_mixed"]) < TOL_OP
+    assert np.abs(np_(px) - g["px"]).max() < TOL_P
+    # library draws: propose runs (no one-launch kernel for this instance) and accepts / rejects row by row
+    Lx2, Lv2, px2, (out2,) = la.propose(x, dyn, do_mh_step=True)
+    assert Lv2 is None and bool(((out2 == Lx2).all(dim=1) | (out2 == _lib_dev(x)).all(dim=1)).all())
+    assert float(px2.min()) >= 0.0 and float(px2.max()) <= 1.0
+
+
+def _lib_dev(a):
+    from l2hmc_amd import _lib
+    return _lib.as_dev(a)
+
+
+class _QuarticTarget:
+    """An energy the packed targets cannot express: E(x) = sum_d (x_d^2 - 1)^2 / 4 + c sum_d x_d x_{d+1} (periodic)."""
+
+    def __init__(self, c):
+        self.c = c
+
+    def energy(self, x):
+        return np.sum((x * x - 1.) ** 2, axis=1) / 4. + self.c * np.sum(x * np.roll(x, -1, axis=1), axis=1)
+
+    def grad_energy(self, x):
+        return (x * x - 1.) * x + self.c * (np.roll(x, -1, axis=1) + np.roll(x, 1, axis=1))
+
+
+@pytest.mark.parametrize("x_dim,nodes,kind", [(12, 100, "gmm"), (20, 128, "callable"), (3, 70, "callable"), (9, 16, "gmm")])
+def test_generic_dynamics_any_energy_any_width(la, x_dim, nodes, kind):
+    """The reference's `Dynamics` takes ANY `energy_function`, x_dim and `net_factory` (utils/dynamics.py:35-43,
+    utils/network.py:89).  Shapes beyond the one-launch kernels (x_dim > 8, more than 64 hidden units) and an energy
+    given as a plain torch callable (gradient by torch.autograd, the reference's tf.gradients) run layer by layer:
+    forward, backward, accept probabilities, the inverse pair and `propose` against the float64 oracle."""
+    from oracle import dynamics as ogen
+    rng = np.random.default_rng(41 + x_dim)
+    N, eps, B = 4, 0.1, 96
+    if kind == "gmm":
+        K = 3
+        mus = [rng.normal(0, 1.0, x_dim) for _ in range(K)]
+        sig = [np.diag(rng.uniform(0.3, 0.8, x_dim)) for _ in range(K)]
+        pis = [0.5, 0.3, 0.2]
+        otgt = ogen.GMM(mus, sig, pis)
+        if x_dim <= 8:
+            fn = la.GMM(mus, sig, pis).get_energy_function()
+        else:                         # beyond the packed targets: the same mixture as a torch function
+            mu_t = torch.tensor(np.stack(mus), dtype=torch.float32, device="cuda")
+            prec_t = torch.tensor(np.stack([np.diag(1. / np.diag(s)) for s in sig]), dtype=torch.float32, device="cuda")
+            lc_t = torch.tensor([np.log(p / np.sqrt((2 * np.pi) ** x_dim * np.linalg.det(s))) for p, s in zip(pis, sig)],
+                                dtype=torch.float32, device="cuda")
+
+            def fn(x):
+                d = x[:, None, :] - mu_t[None]
+                q = -0.5 * torch.einsum("bkd,kde,bke->bk", d, prec_t, d) + lc_t[None]
+                return -torch.logsumexp(q, dim=1)
+    else:
+        otgt = _QuarticTarget(0.3)
+
+        def fn(x):
+            return ((x * x - 1.) ** 2).sum(dim=1) / 4. + 0.3 * (x * torch.roll(x, -1, dims=1)).sum(dim=1)
+    xp, vp = H.mlp_weights(x_dim, nodes, seed=7, regime="stress")
+    masks = ogen.make_masks(N, x_dim, np.random.RandomState(3))
+    orc = ogen.DynamicsOracle(x_dim, otgt, N, eps, masks, xp, vp)
+    dyn = la.Dynamics(x_dim, fn, trajectory_length=N, eps=eps,
+                      net_factory=lambda d, scope, factor: la.network(d, scope, factor, num_nodes=nodes))
+    assert dyn.layered
+    dyn.set_masks(masks)
+    dyn.XNet.load_state(xp)
+    dyn.VNet.load_state(vp)
+    x = rng.normal(0, 0.8, (B, x_dim))
+    v0 = rng.standard_normal((B, x_dim))
+    assert H.relerr(np_(dyn.energy(x)), orc.energy(x)) < 2e-5
+    assert H.relerr(np_(dyn.grad_energy(x)), orc.grad_energy(x)) < TOL_OP
+    Xf, Vf, pf = dyn.forward(x, init_v=v0)
+    Xb, Vb, pb = dyn.backward(x, init_v=v0)
+    wf, wb = orc.forward(x, v0), orc.backward(x, v0)
+    for got, want in ((Xf, wf[0]), (Vf, wf[1]), (Xb, wb[0]), (Vb, wb[1])):
+        assert H.relerr(np_(got), want) < 2 * TOL_OP
+    assert np.abs(np_(pf) - wf[2]).max() < TOL_P and np.abs(np_(pb) - wb[2]).max() < TOL_P
+    assert float(pf.mean()) > 0.01
+    # backward undoes forward and the log-determinants cancel (utils/dynamics.py:172-225)
+    Xr, Vr, ljb = dyn.backward(Xf, init_v=Vf, log_jac=True)
+    _, _, ljf = dyn.forward(x, init_v=v0, log_jac=True)
+    assert H.relerr(np_(Xr), x) < 1e-4 and H.relerr(np_(Vr), v0) < 1e-4
+    assert float((ljf + ljb).abs().max()) < 1e-4 * max(1.0, float(ljf.abs().max()))
+    dir_bits, u = rng.integers(0, 2, B).astype(np.float32), rng.uniform(size=B)
+    Lx, Lv, px, (out,) = la.propose(x, dyn, init_v=v0, do_mh_step=True, init_v_backward=v0, dir_bits=dir_bits, u=u)
+    want = ogen.propose(x, orc, v0, v0, dir_bits, u=u, do_mh_step=True)
+    assert H.relerr(np_(Lx), want[0]) < 2 * TOL_OP and np.abs(np_(px) - want[2]).max() < TOL_P
 
 
 @pytest.mark.parametrize("name,B", [("mog_cfg2", 4096), ("mog_cfg2", 37), ("scg_cfg1", 128)])
