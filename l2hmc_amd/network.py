@@ -187,6 +187,13 @@ class _DenseSTQ:
             self._packed = (st, bufs)
         return self._packed[0]
 
+    def flat_tensors(self):
+        """The packed device buffers in the field order of struct l2hmc_dense_net (w1_t, wt, b1, wh_t, bh, whd_t, bhd,
+        coeff_s, coeff_q): what torch.ops.l2hmc.stq_dense takes as `weights` (l2hmc_amd/torch_ops.py)."""
+        self.pack()
+        bufs = self._packed[1]
+        return [bufs[k] for k in ("w1_t", "wt", "b1", "wh_t", "bh", "whd_t", "bhd", "coeff_s", "coeff_q")]
+
     # ---- standalone evaluation: (S, T, Q) = net([a, b, t])
     def __call__(self, inputs):
         a, b, t = inputs[0], inputs[1], inputs[2]

@@ -38,6 +38,18 @@ def test_library_exports_nothing_the_header_does_not_declare(L):
     assert "getenv" not in und
 
 
+def test_torch_ops_are_registered_and_have_no_cpu_implementation():
+    """the stateless operators are also visible as torch.ops.l2hmc.* (l2hmc_amd/torch_ops.py, thin
+    dispatchers onto the C ABI); a CPU tensor raises -- there is no CPU path behind them either."""
+    import l2hmc_amd.torch_ops as T
+    for name in T.OPS:
+        assert hasattr(torch.ops.l2hmc, name), name
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.l2hmc.kinetic_energy(torch.zeros(3, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.l2hmc.u1_action_force(torch.zeros(2, 128), 8, 8, 2.0)
+
+
 def test_struct_layouts_match_the_c_header(tmp_path):
     """sizeof/offsetof as gcc sees include/l2hmc_hip.h vs the ctypes mirrors: a mismatch would corrupt every call."""
     import subprocess

@@ -590,6 +590,51 @@ def _lib_dev(a):
     return _lib.as_dev(a)
 
 
+def test_torch_ops_dispatch_to_the_same_kernels(la):
+    """torch.ops.l2hmc.* (l2hmc_amd/torch_ops.py) against the class surface: same library entries, same bits."""
+    import l2hmc_amd.torch_ops  # noqa: F401 -- registers the operators
+    from l2hmc_amd import _lib
+    ops = torch.ops.l2hmc
+    rng = np.random.default_rng(17)
+    T = X = 8
+    B, D = 96, 128
+    x = torch.as_tensor(rng.uniform(0, 2 * np.pi, (B, D)), dtype=torch.float32, device="cuda")
+    v = torch.as_tensor(rng.standard_normal((B, D)), dtype=torch.float32, device="cuda")
+    want = la.u1_observables(x, T, X, beta=2.0, want_force=True)
+    action, force, plaq, charge = ops.u1_action_force(x, T, X, 2.0)
+    assert torch.equal(action, want["action"]) and torch.equal(force, want["force"])
+    assert torch.equal(plaq, want["avg_plaq"]) and torch.equal(charge, want["top_charge"])
+    xp, _ = H.gauge_weights(T, X, regime="mild")
+    net = la.GenericNet(model_name='XNet', x_dim=D, num_hidden=4 * D, factor=2., name_scope='position', links_shape=(T, X, 2))
+    net.load_state(xp)
+    tt = np.array([[0.3, 0.95]])
+    S0, T0, Q0 = net([v, x, tt])
+    S, Tr, Q = ops.stq_dense(v, x, net.flat_tensors(), net.q_tanh, float(np.float32(0.3)), float(np.float32(0.95)))
+    assert torch.equal(S, S0) and torch.equal(Tr, T0) and torch.equal(Q, Q0)
+    keep = torch.as_tensor((rng.uniform(size=D) < 0.5).astype(np.float32), device="cuda")
+    for d in (0, 1):
+        v1, ld = ops.lf_update_v(v, force, S, Tr, Q, 0.1, d)
+        x1, ld2 = ops.lf_update_x(x, v1, keep, S, Tr, Q, 0.1, d)
+        ref_v, ref_ld = torch.empty_like(v), torch.empty(B, device="cuda")
+        _lib.check(_lib.lib().l2hmc_lf_update_v(v.data_ptr(), force.data_ptr(), S.data_ptr(), Tr.data_ptr(), Q.data_ptr(),
+                                                0.1, d, B, D, ref_v.data_ptr(), ref_ld.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(v1, ref_v) and torch.equal(ld, ref_ld)
+        assert torch.equal(x1[:, keep > 0.5], x[:, keep > 0.5]) and bool(torch.isfinite(ld2).all())
+    k = ops.kinetic_energy(v)
+    assert H.relerr(np_(k), 0.5 * (np_(v).astype(np.float64) ** 2).sum(1)) < 1e-6
+    p = ops.accept_prob(k, k + 0.5, torch.zeros_like(k))
+    assert H.relerr(np_(p), np.full(B, np.exp(-0.5))) < 1e-6
+    y = ops.wrap_angle(x + 7.0)
+    assert float(y.min()) >= 0.0 and float(y.max()) < 2 * np.pi + 1e-6
+    coin = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
+    u = torch.as_tensor(rng.uniform(size=B), dtype=torch.float32, device="cuda")
+    xpz, vpz, pz, xo = ops.mix_accept(x, x1, v1, p, x, v, p * 0.5, coin, u, 1)
+    fwd = coin > 0.5
+    assert torch.equal(xpz[fwd], x1[fwd]) and torch.equal(xpz[~fwd], x[~fwd])
+    acc = pz > u
+    assert torch.equal(xo[acc], xpz[acc]) and torch.equal(xo[~acc], x[~acc])
+
+
 class _QuarticTarget:
     """An energy the packed targets cannot express: E(x) = sum_d (x_d^2 - 1)^2 / 4 + c sum_d x_d x_{d+1} (periodic)."""
 
