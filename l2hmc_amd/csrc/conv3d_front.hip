@@ -321,7 +321,7 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
 // NTHR: threads per workgroup.  The phases are chains of dependent LDS reads; at 16 x 16 / F = 16 a chain's maps take
 // 59 KB (two workgroups per CU), so that instance runs 512 threads per workgroup to have four waves per SIMD in flight.
 template <int FT, int LT, int NTHR = kConvThreads>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) void conv3d_front_bwd_kernel(
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 8))) void conv3d_front_bwd_kernel(
     ConvBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = blockIdx.y;
@@ -345,9 +345,12 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
   //  per (position, filter) and dep1 says which depth it belongs to -- half the LDS, more resident workgroups)
   float* G1 = dpre1 + cpw * T2 * X2 * F;           // [cpw][TP][XP][F]    conv1 output (i, j) at (i + 1, j + 1)
   const int nent = 18 * F + F + 4 * F * F2 + F2;   // compact gradient entries: w1 | b1 | w2 (dd = 0 slice) | b2
-  float* G2 = G1 + cpw * max(TP * XP * F, nent);   // [cpw][T2P][X2P][2F] conv2 output (i2, j2) at (i2 + 1, j2 + 1)
+  // (compile-time instances pad a G2 position to 2F + 4 floats: the matrix-pipe form of phase 3 reads it with 16-byte
+  //  loads at a stride of one position per lane, and 36 / 20 floats spread sixteen lanes over all 64 banks)
+  const int G2S = FT > 0 ? F2 + 4 : F2;
+  float* G2 = G1 + cpw * max(TP * XP * F, nent);   // [cpw][T2P][X2P][G2S] conv2 output (i2, j2) at (i2 + 1, j2 + 1)
   float* pw = G1;                                  // [cpw][nent] per-chain contributions: phase 5, when G1 is dead
-  unsigned char* arg1 = reinterpret_cast<unsigned char*>(G2 + cpw * T2P * X2P * F2);   // [cpw][T2][X2][F] winners
+  unsigned char* arg1 = reinterpret_cast<unsigned char*>(G2 + cpw * T2P * X2P * G2S);  // [cpw][T2][X2][F] winners
   unsigned char* dep1 = arg1 + ((cpw * T2 * X2 * F + 15) & ~15);                      // [cpw][TP][XP][F] depth of G1
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * cpw;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
   for (int i = tid; i < F2; i += NTHR) b2[i] = p.b2[which][i];
   {
     // xin | p1 | dpre1 | G1 | G2 are contiguous and each a multiple of four floats: one 16-byte sweep clears the halos
-    const int nz4 = (int)((G2 + cpw * T2P * X2P * F2) - xin) / 4;
+    const int nz4 = (int)((G2 + cpw * T2P * X2P * G2S) - xin) / 4;
     for (int i = tid; i < nz4; i += NTHR) reinterpret_cast<f32x4*>(xin)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // this workgroup's gradient slot is read now and written at the very end: its round trip hides under the phases
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
-        G2[((c * T2P + 2 * I2 + a + 1) * X2P + 2 * J2 + bb + 1) * F2 + g] = (code == a * 2 + bb) ? dv : 0.f;
+        G2[((c * T2P + 2 * I2 + a + 1) * X2P + 2 * J2 + bb + 1) * G2S + g] = (code == a * 2 + bb) ? dv : 0.f;
   }
   __syncthreads();
 
@@ -487,7 +490,55 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
   // ---- phase 3: transposed conv2 (dense, no winner tests): gradient of the pooled conv1 map, gated by its own relu /
   // winner, then spread over the cell's eight pre-pooling outputs in G1.  conv2 output (i2, j2) reads p1(i2 + di,
   // j2 + dj), so p1 cell (I, J) collects output (I - di, J - dj) through tap (di, dj).
-  for (int idx = tid; idx < n1; idx += NTHR) {
+  // Compile-time instances run the product on the matrix pipe (round 4): per chain a [T2 X2 positions] x [4 taps x 2F
+  // filters] x [F channels] product, v_mfma_f32_16x16x4_f32 on tiles of 16 positions x 16 channels, lane (q, r) reading
+  // sixteen bytes of position r's G2 row (four consecutive filters = four k-steps) per tap and 16-filter group, the
+  // filter fragments held in registers for all of a wave's tiles.  The VALU form below issued two 16-byte LDS reads per
+  // four multiply-adds and was LDS-bandwidth-bound: 25 % of the kernel at 16 x 16 (profiles/r04_conv_bwd_stamps.txt).
+  if constexpr (FT > 0) {
+    constexpr int F_ = FT, F2_ = 2 * FT, X2_ = LT / 2, NP = (LT / 2) * (LT / 2), MT3 = NP / 16, NS = F2_ / 16;
+    static_assert(NP % 16 == 0 && F_ <= 16, "transposed conv2 tiles");
+    const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
+    // (the filter fragments w2[tap][channel r][16 s + 4 q ...] are re-read per tap: held for all four taps they push
+    //  the kernel past 128 registers, i.e. from two workgroups per CU to one -- measured: no faster than the VALU form)
+    for (int item = wave; item < nrow * MT3; item += NTHR / 64) {
+      const int c = item / MT3, mt = item - c * MT3;
+      const int pr = mt * 16 + r, Ir = pr / X2_, Jr = pr - Ir * X2_;          // this lane's operand row (a p1 cell)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const float* gq = G2 + ((c * T2P + Ir - (tap >> 1) + 1) * X2P + Jr - (tap & 1) + 1) * G2S + 4 * q;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(gq + 16 * s);
+          const f32x4 w4 = r < F_ ? *reinterpret_cast<const f32x4*>(w2 + (tap * F_ + r) * F2_ + 16 * s + 4 * q)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};          // zero columns beyond the F channels
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], w4[e], acc, 0, 0, 0);
+        }
+      }
+      // C layout: row 4 q + e = position, column r = channel
+      if (r < F_) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pp = mt * 16 + 4 * q + e, I = pp / X2_, J = pp - I * X2_;
+          const int idx = ((c * T2 + I) * X2 + J) * F + r;
+          const int code = arg1[idx];
+          const float dp = code != 255 ? acc[e] : 0.f;
+          dpre1[idx] = dp;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              const int pos = ((c * TP + 2 * I + a + 1) * XP + 2 * J + bb + 1) * F + r;
+              G1[pos] = ((code >> 1) == a * 2 + bb) ? dp : 0.f;
+              dep1[pos] = (unsigned char)(code & 1);
+            }
+        }
+      }
+    }
+  }
+  for (int idx = tid; idx < (FT > 0 ? 0 : n1); idx += NTHR) {
     const int ch = idx % F;
     int r = idx / F;
     const int J = r % X2;
@@ -501,7 +552,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
       for (int di = 0; di < 2; ++di)
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
-          const float* gq = G2 + ((c * T2P + I - di + 1) * X2P + J - dj + 1) * F2;
+          const float* gq = G2 + ((c * T2P + I - di + 1) * X2P + J - dj + 1) * G2S;
           const float* kw = w2 + ((di * 2 + dj) * F + ch) * F2;
           for (int g4 = 0; g4 < F2; g4 += 4)
             s4 += *reinterpret_cast<const f32x4*>(gq + g4) * *reinterpret_cast<const f32x4*>(kw + g4);
@@ -524,7 +575,12 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
   // ---- phase 4: transposed conv1 (dense): gradient of the raw input, both link directions of a site per thread.
   // conv1 output (i, j) reads x(i + di - 1, j + dj - 1) (zero padding: no periodic wrap, as the forward); depth 0
   // sees (mu = 0, mu = 1) through (k0, k1) = w1[tap][dd = 0 | 1], depth 1 sees mu = 1 through k0.
-  for (int sidx = tid; sidx < nrow * T * X; sidx += NTHR) {
+  // A site's sum over the filters is shared by FS adjacent lanes (compile-time instances with one chain per workgroup
+  // have fewer sites than threads: 256 sites on 512 threads at 16 x 16), each walking every FS-th group of four
+  // filters; the lanes' partial sums meet in a fixed-order butterfly.
+  constexpr int FS = (FT > 0 && (FT / 4) % 2 == 0 && LT * LT <= NTHR / 2) ? 2 : 1;
+  for (int sidx0 = tid; sidx0 < nrow * T * X * FS; sidx0 += NTHR) {
+    const int sidx = sidx0 / FS, fpart = sidx0 - sidx * FS;
     const int c = sidx / (T * X), site = sidx - c * (T * X);
     const int ip = site / X, jp = site - ip * X;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -534,7 +590,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
       for (int dj = 0; dj < 3; ++dj) {
         const int pos = ((c * TP + ip - di + 2) * XP + jp - dj + 2) * F;                // output (ip - di + 1, jp - dj + 1)
         const float* k = w1 + (di * 3 + dj) * 2 * F;
-        for (int f4 = 0; f4 < F; f4 += 4) {
+        for (int f4 = 4 * fpart; f4 < F; f4 += 4 * FS) {
           const f32x4 gv = *reinterpret_cast<const f32x4*>(G1 + pos + f4);
           const unsigned dm = *reinterpret_cast<const unsigned*>(dep1 + pos + f4);        // four depth bytes
           const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + f4), k1 = *reinterpret_cast<const f32x4*>(k + F + f4);
@@ -546,9 +602,16 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
           }
         }
       }
-    float* o = p.din + (row0 + c) * p.ldd + which * D + 2 * site;
-    o[0] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-    o[1] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    float s0 = (a0[0] + a0[1]) + (a0[2] + a0[3]), s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    if constexpr (FS == 2) {             // (nrow * T * X * FS is a multiple of 2: both lanes of a pair are here)
+      s0 += __shfl_xor(s0, 1, 64);
+      s1 += __shfl_xor(s1, 1, 64);
+    }
+    if (fpart == 0) {
+      float* o = p.din + (row0 + c) * p.ldd + which * D + 2 * site;
+      o[0] = s0;
+      o[1] = s1;
+    }
   }
 
   __syncthreads();                   // pw aliases G1
@@ -557,36 +620,119 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
   // contribution to LDS; one owner thread per entry then adds the chains in order into the workgroup's slot.
   //   w1 / b1: item (chain, tap, f) walks the chain's pooling cells of filter f once and feeds both dd entries;
   //   w2 / b2: item (chain, tap, ch, 4 g) is a dense sum over the conv2 output positions (G2 holds zeros off-winner).
+  // conv1 filter / bias gradient.  Every pooling cell is a chain of dependent LDS reads (winner byte -> the input pair
+  // it points at), and an item that walks all T2 X2 cells of its (chain, tap, filter) is latency-bound with 9 F of the
+  // workgroup's threads busy (36 % of the kernel at 16 x 16 after phases 3 and 5b went to the matrix pipe).  Where
+  // the dead G1 map has room behind pw (the 16 x 16 instance), an item owns ONE ROW of cells -- T2 times the items,
+  // chains of X2 instead of T2 X2 -- and leaves a partial sum; owners then add the T2 partials in row order.
+  constexpr bool kRowItems = FT > 0 && (LT + 2) * (LT + 2) * FT - (19 * FT + 8 * FT * FT + 2 * FT) >= (LT / 2) * 19 * FT;
+  if constexpr (kRowItems) {
+    constexpr int F_ = FT, T2_ = LT / 2, X2_ = LT / 2;
+    float* wpart = pw + cpw * nent;                          // [cpw][T2][19][F]: 18 filter rows + the bias row
+    const int nit = nrow * T2_ * 9 * F_;
+    for (int item = tid; item < nit; item += NTHR) {
+      const int f = item % F_;
+      int rr = item / F_;
+      const int tap = rr % 9;
+      rr /= 9;
+      const int I = rr % T2_, c = rr / T2_;
+      const int di = tap / 3, dj = tap - di * 3;
+      float s0 = 0.f, s1 = 0.f, sb = 0.f;
+#pragma unroll
+      for (int J = 0; J < X2_; ++J) {
+        const int cell = ((c * T2_ + I) * X2_ + J) * F_ + f;
+        const int code = arg1[cell] & 7;                     // (a dead cell has dpre1 = 0 and decodes to a valid position)
+        const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
+        const float* px = xin + ((c * TP + 2 * I + a + di) * XP + 2 * J + bb + dj) * 2;
+        const float dpv = dpre1[cell], x0 = px[0], x1 = px[1];
+        s0 += dpv * (depth ? x1 : x0);
+        s1 += depth ? 0.f : dpv * x1;
+        sb += dpv;
+      }
+      float* o = wpart + (c * T2_ + I) * 19 * F_ + f;
+      o[(tap * 2 + 0) * F_] = s0;
+      o[(tap * 2 + 1) * F_] = s1;
+      if (tap == 0) o[18 * F_] = sb;
+    }
+    __syncthreads();
+    for (int ent = tid; ent < nrow * 19 * F_; ent += NTHR) {
+      const int c = ent / (19 * F_), e = ent - c * 19 * F_;
+      float sum = 0.f;
+#pragma unroll
+      for (int I = 0; I < T2_; ++I) sum += wpart[(c * T2_ + I) * 19 * F_ + e];
+      pw[c * nent + e] = sum;                                // entries [0, 18 F): conv1 filter, [18 F, 19 F): its bias
+    }
+  }
   {
-    const int nw1 = nrow * 9 * F;
+    const int nw1 = kRowItems ? 0 : nrow * 9 * F;
     for (int item = tid; item < nw1; item += NTHR) {
       const int f = item % F;
       int r = item / F;
       const int tap = r % 9, c = r / 9;
       const int di = tap / 3, dj = tap - di * 3;
       float s0 = 0.f, s1 = 0.f;
-      for (int I = 0; I < T2; ++I)
-        for (int J = 0; J < X2; ++J) {
-          // branch-free: a dead cell (code 255) has dpre1 = 0 and decodes to a valid position
-          const int cell = ((c * T2 + I) * X2 + J) * F + f;
-          const int code = arg1[cell] & 7;
-          const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
-          const float* px = xin + ((c * TP + 2 * I + a + di) * XP + 2 * J + bb + dj) * 2;
-          const float dpv = dpre1[cell], x0 = px[0], x1 = px[1];
-          s0 += dpv * (depth ? x1 : x0);           // dd = 0: depth 0 reads mu = 0, depth 1 reads mu = 1
-          s1 += depth ? 0.f : dpv * x1;            // dd = 1: only depth 0 (mu = 1); depth 1 reads the padding
-        }
+      // (one flat loop, unrolled: every cell is a chain of dependent LDS reads -- winner byte, then the input pair it
+      //  points at -- and the cells are independent; eight in flight instead of one)
+#pragma unroll 2
+      for (int IJ = 0; IJ < T2 * X2; ++IJ) {
+        const int I = IJ / X2, J = IJ - I * X2;
+        // branch-free: a dead cell (code 255) has dpre1 = 0 and decodes to a valid position
+        const int cell = (c * T2 * X2 + IJ) * F + f;
+        const int code = arg1[cell] & 7;
+        const int a = code >> 2, bb = (code >> 1) & 1, depth = code & 1;
+        const float* px = xin + ((c * TP + 2 * I + a + di) * XP + 2 * J + bb + dj) * 2;
+        const float dpv = dpre1[cell], x0 = px[0], x1 = px[1];
+        s0 += dpv * (depth ? x1 : x0);           // dd = 0: depth 0 reads mu = 0, depth 1 reads mu = 1
+        s1 += depth ? 0.f : dpv * x1;            // dd = 1: only depth 0 (mu = 1); depth 1 reads the padding
+      }
       pw[c * nent + (tap * 2 + 0) * F + f] = s0;
       pw[c * nent + (tap * 2 + 1) * F + f] = s1;
     }
-    for (int item = tid; item < nrow * F; item += NTHR) {
+    for (int item = tid; item < (kRowItems ? 0 : nrow * F); item += NTHR) {
       const int f = item % F, c = item / F;
       float sb = 0.f;
       for (int cell = c * T2 * X2; cell < (c + 1) * T2 * X2; ++cell) sb += dpre1[cell * F + f];
       pw[c * nent + 18 * F + f] = sb;
     }
+    // conv2 filter gradient: per chain and tap dW[ch][g] = sum over the conv2 output positions of
+    // p1(pos + tap)[ch] * G2(pos)[g] -- a product with the POSITIONS as contraction index.  Compile-time instances
+    // run it on the matrix pipe (round 4): v_mfma_f32_16x16x4_f32 with rows = (tap, channel) (one tap per 16-row
+    // tile at F = 16, two at F = 8), columns = 16 output filters, k = four consecutive positions; both operands are
+    // read as they lie in LDS (a lane's operand is one float: sixteen lanes read sixteen consecutive channels /
+    // filters of one position) -- 48 four-byte LDS reads per 32 MFMAs where the VALU form below issues two reads
+    // per four multiply-adds (it was 41 % of the kernel at 16 x 16 by in-kernel stamps, profiles/r04_conv_bwd_stamps.txt).
+    if constexpr (FT > 0) {
+      constexpr int F_ = FT, F2_ = 2 * FT, X2_ = LT / 2, NP = (LT / 2) * (LT / 2);
+      constexpr int TPM = 16 / F_, MTL = 4 / TPM, NTN = F2_ / 16;
+      static_assert(16 % F_ == 0 && F2_ % 16 == 0 && NP % 4 == 0 && X2_ % 4 == 0, "conv2 filter gradient tiles");
+      const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, r = lane & 15;
+      for (int item = wave; item < nrow * MTL; item += NTHR / 64) {
+        const int c = item / MTL, mt = item - c * MTL;
+        const int tap = mt * TPM + r / F_, ch = r % F_;          // this lane's operand row
+        const float* ap = p1 + ((c * T2P + (tap >> 1)) * X2P + (tap & 1)) * F_ + ch;
+        const float* bp = G2 + ((c * T2P + 1) * X2P + 1) * G2S + r;
+        f32x4 acc[NTN];
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < NP / 4; ++ks) {
+          const int k = 4 * ks + q, i2 = k / X2_, j2 = k - i2 * X2_;      // position k of the chain's conv2 output
+          const float av = ap[(i2 * X2P + j2) * F_];
+#pragma unroll
+          for (int nt = 0; nt < NTN; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[(i2 * X2P + j2) * G2S + 16 * nt], acc[nt], 0, 0, 0);
+        }
+        // C layout: row 4 q + e, column r
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int mrow = 4 * q + e, tap_o = mt * TPM + mrow / F_, ch_o = mrow % F_;
+#pragma unroll
+          for (int nt = 0; nt < NTN; ++nt) pw[c * nent + 19 * F_ + (tap_o * F_ + ch_o) * F2_ + 16 * nt + r] = acc[nt][e];
+        }
+      }
+    }
     const int g4n = F2 / 4;
-    const int nw2 = nrow * 4 * F * g4n;
+    const int nw2 = FT > 0 ? 0 : nrow * 4 * F * g4n;
     for (int item = tid; item < nw2; item += NTHR) {
       const int g4 = (item % g4n) * 4;
       int r = item / g4n;
@@ -597,7 +743,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
       for (int i2 = 0; i2 < T2; ++i2)
         for (int j2 = 0; j2 < X2; ++j2)
-          s4 += *reinterpret_cast<const f32x4*>(G2 + ((c * T2P + i2 + 1) * X2P + j2 + 1) * F2 + g4) *
+          s4 += *reinterpret_cast<const f32x4*>(G2 + ((c * T2P + i2 + 1) * X2P + j2 + 1) * G2S + g4) *
                 p1[((c * T2P + i2 + di) * X2P + j2 + dj) * F + ch];
       *reinterpret_cast<f32x4*>(pw + c * nent + 19 * F + (tap * F + ch) * F2 + g4) = s4;
     }
@@ -605,7 +751,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
       const int g = item % F2, c = item / F2;
       float sb = 0.f;
       for (int i2 = 0; i2 < T2; ++i2)
-        for (int j2 = 0; j2 < X2; ++j2) sb += G2[((c * T2P + i2 + 1) * X2P + j2 + 1) * F2 + g];
+        for (int j2 = 0; j2 < X2; ++j2) sb += G2[((c * T2P + i2 + 1) * X2P + j2 + 1) * G2S + g];
       pw[c * nent + 19 * F + 4 * F * F2 + g] = sb;
     }
   }
@@ -646,12 +792,14 @@ int launch_conv3d_front_bwd(ConvBwdArgs& a, hipStream_t stream) {
 #endif
   const size_t F = a.F, F2 = 2 * F, cpw = a.cpw, TP = a.T + 2, XP = a.X + 2, T2 = a.T / 2, X2 = a.X / 2;
   const size_t cells1 = cpw * T2 * X2 * F, nent = 18 * F + F + 4 * F * F2 + F2;
+  const bool fixed = (a.F == 8 && a.T == 8 && a.X == 8) || (a.F == 16 && a.T == 16 && a.X == 16);   // compile-time instances
+  const size_t g2s = fixed ? F2 + 4 : F2;                                      // (kernel: G2S)
   const size_t lds = sizeof(float) * (18 * F + F + 4 * F * F2 + F2 +           // filters
                                       cpw * TP * XP * 2 +                       // xin
                                       cpw * (T2 + 1) * (X2 + 1) * F +           // p1
                                       cells1 +                                  // dpre1
                                       cpw * (TP * XP * F > nent ? TP * XP * F : nent) +   // G1, later pw
-                                      cpw * (T2 + 1) * (X2 + 1) * F2) +         // G2
+                                      cpw * (T2 + 1) * (X2 + 1) * g2s) +        // G2
                      align_up(cells1, 16) + align_up(cpw * TP * XP * F, 16);    // arg1, dep1
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end backward: %zu B of LDS needed", lds);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), 2);
