@@ -396,8 +396,9 @@ typedef struct l2hmc_mog_target {
 typedef struct l2hmc_small_plan {
   int32_t x_dim, num_nodes, trajectory_length, hmc;
   float eps;
-  int32_t first_layer_form;        /* 0: chosen by batch size; 1 / 2: force the matrix-pipe / VALU form of the first layer
-                                    * (they walk the hidden layer's k in different orders and agree to rounding) */
+  int32_t first_layer_form;        /* 0: chosen by batch size; 1 / 2: force the matrix-pipe / VALU form of the first layer;
+                                    * 3: two waves per group of 16 rows (latency form, 17..64 hidden units).  The forms
+                                    * group their sums differently and agree to rounding */
   const float* masks;              /* [trajectory_length][x_dim] */
   l2hmc_dense_net xnet, vnet;      /* q_tanh = 1, Ka = Kb = x_dim */
   l2hmc_mog_target target;

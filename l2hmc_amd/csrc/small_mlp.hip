@@ -190,6 +190,134 @@ __device__ void load_net_mfma(const l2hmc_dense_net& n, float* L, int dim) {
 // in registers in the latency form (L1M: one wave per SIMD by design; 101 -> 92 us per cfg-2 propose), in LDS in the
 // throughput form (in registers they pushed it past 256, i.e. from two waves per SIMD to one: 0.57 -> 0.81 ms at
 // 65536 chains)
+// TW ("twin", round 4; latency form only, HP = 64): TWO waves integrate the same 16 rows.  Both form the whole first
+// layer; wave `part` owns the hidden layer's output tiles 2 part, 2 part + 1 -- i.e. the hidden units that are k-steps
+// [8 part, 8 part + 8) of the heads -- and the heads' partial sums over those steps; the two partial sums meet through
+// LDS once per network call (net_eval_mfma).  Per call a wave issues 2 NT + 2 K2 + 8 NTH matrix instructions instead of
+// 2 NT + 4 K2 + KSH NTH (cfg 2: 44 instead of 78), and at cfg 2 the 1024 waves have a SIMD each (512 waves before).
+template <int HP, int MD, int KS_, int KSH_>
+struct NetRegsTwin {
+  using V = MfmaNet<HP, MD, KS_, KSH_>;
+  static_assert(V::NT == 4, "the twin form splits four hidden tiles over two waves");
+  static constexpr int K2 = V::KSH, KO = 8;                  // hidden-layer k-steps; heads k-steps owned by a wave
+  float w1[V::NT * V::KS1];
+  float w2[2 * K2];                     // own tiles: [tile-local][s]
+  float whd[V::NTH * KO];               // own heads steps: global step 8 part + j (zero beyond KSH)
+  float bh[KO];                         // bias of own unit at own step j
+  float bhd[V::NTH * 4];
+  float es[MD], eq[MD];
+  __device__ __forceinline__ void load(const float* L, int lane, int part) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < KO; ++j) {
+      const int s = 8 * part + j;
+      bh[j] = s < V::KSH ? L[V::bh + 16 * (s >> 2) + 4 * q + (s & 3)] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < V::NTH; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bhd[4 * t + e] = L[V::bhd + 16 * t + 4 * q + e];
+#pragma unroll
+    for (int d = 0; d < MD; ++d) {
+      es[d] = L[V::es + d];
+      eq[d] = L[V::eq + d];
+    }
+#pragma unroll
+    for (int i = 0; i < V::NT * V::KS1; ++i) w1[i] = L[V::w1 + i * 64 + lane];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int s = 0; s < K2; ++s) w2[tl * K2 + s] = L[V::w2 + ((2 * part + tl) * K2 + s) * 64 + lane];
+#pragma unroll
+    for (int th = 0; th < V::NTH; ++th)
+#pragma unroll
+      for (int j = 0; j < KO; ++j) {
+        const int s = 8 * part + j;
+        whd[th * KO + j] = s < V::KSH ? L[V::whd + (th * V::KSH + s) * 64 + lane] : 0.f;
+      }
+  }
+};
+
+// (S, T, Q) of the twin form: as net_eval_mfma's L1M path, with the hidden layer and the heads split over the two waves
+// of a group.  xch: this group's exchange patch [2 call parities][2 parts][NTH][64 lanes] of 16 bytes; every wave of the
+// workgroup calls this the same number of times (one workgroup barrier per call).
+template <int HP, int MD, int KS_, int KSH_>
+__device__ __forceinline__ void net_eval_twin(const NetRegsTwin<HP, MD, KS_, KSH_>& W, int dim, int q_tanh,
+                                              const float (&a)[MD], const float (&b)[MD], float tc, float ts, int lane,
+                                              int part, f32x4s* xch, int parity, float (&S)[MD], float (&T)[MD],
+                                              float (&Q)[MD]) {
+  using V = MfmaNet<HP, MD, KS_, KSH_>;
+  constexpr int NT = V::NT, NTH = V::NTH, KS1 = V::KS1, K2 = V::KSH, KO = 8;
+  const int q = lane >> 4, r = lane & 15;
+  // ---- layer 1, whole (both waves need every hidden unit as k of layer 2)
+  f32x4s acc[NT];
+#pragma unroll
+  for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    float e4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * s + j;           // compile-time
+      e4[j] = k < MD ? a[k < MD ? k : 0] : k < 2 * MD ? b[(k >= MD && k < 2 * MD) ? k - MD : 0]
+              : k == 2 * MD ? tc : k == 2 * MD + 1 ? ts : k == 2 * MD + 2 ? 1.f : 0.f;
+    }
+    const float mine = q == 0 ? e4[0] : q == 1 ? e4[1] : q == 2 ? e4[2] : e4[3];
+#pragma unroll
+    for (int to = 0; to < NT; ++to)
+      acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[to * KS1 + s], mine, acc[to], 0, 0, 0);
+  }
+  float h1[K2];
+#pragma unroll
+  for (int s = 0; s < K2; ++s) h1[s] = fmaxf(acc[s >> 2][s & 3], 0.f);
+  // ---- layer 2, own two tiles
+  f32x4s a2[2] = {f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = 0; s < K2; ++s)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+      a2[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[tl * K2 + s], h1[s], a2[tl], 0, 0, 0);
+  float h2[KO];
+#pragma unroll
+  for (int j = 0; j < KO; ++j) h2[j] = fmaxf(a2[j >> 2][j & 3] + W.bh[j], 0.f);
+  // ---- heads: partial sums over the own k-steps, exchanged through LDS, added part 0 first in BOTH waves
+  f32x4s* mine = xch + (parity * 2 + part) * NTH * 64 + lane;
+  const f32x4s* other = xch + (parity * 2 + (part ^ 1)) * NTH * 64 + lane;
+  f32x4s hv[NTH];
+#pragma unroll
+  for (int th = 0; th < NTH; ++th) {
+    f32x4s c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int j = 0; j < KO; ++j) {
+      if (j & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KO + j], h2[j], c1, 0, 0, 0);
+      else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.whd[th * KO + j], h2[j], c0, 0, 0, 0);
+    }
+    hv[th] = c0 + c1;
+    mine[th * 64] = hv[th];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int th = 0; th < NTH; ++th) {
+    const f32x4s o = other[th * 64];
+    const f32x4s bias = f32x4s{W.bhd[4 * th], W.bhd[4 * th + 1], W.bhd[4 * th + 2], W.bhd[4 * th + 3]};
+    hv[th] = (part ? o + hv[th] : hv[th] + o) + bias;
+  }
+  float out[3 * MD];
+#pragma unroll
+  for (int o = 0; o < 3 * MD; ++o) {
+    const int src = 16 * ((o & 15) >> 2) + r;
+    out[o] = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(hv[o >> 4][o & 3])));
+  }
+#pragma unroll
+  for (int d = 0; d < MD; ++d) {
+    if (d < dim) {
+      S[d] = fast_tanh(out[d]) * W.es[d];
+      T[d] = out[MD + d];
+      Q[d] = (q_tanh ? fast_tanh(out[2 * MD + d]) : out[2 * MD + d]) * W.eq[d];
+    }
+  }
+}
+
 template <int HP, int MD, int KS_, int KSH_, bool L1M>
 struct NetRegs {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
@@ -406,9 +534,10 @@ struct TargetRegs {
   }
 };
 
-template <int HP, int MD, int KS_, int KSH_, bool L1M>
+template <int HP, int MD, int KS_, int KSH_, bool L1M, bool TW = false>
 __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTrajArgs a) {
   using V = MfmaNet<HP, MD, KS_, KSH_>;
+  static_assert(!TW || (L1M && V::NT == 4), "the twin form is a latency form of the 64-unit instances");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const l2hmc_small_plan& P = a.plan;
   const int dim = P.x_dim, N = P.trajectory_length;
@@ -433,14 +562,26 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   __syncthreads();                                // the only workgroup barrier of the kernel
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  NetRegs<HP, MD, KS_, KSH_, L1M> Wx, Wv;
+  // twin form: waves 2 g, 2 g + 1 of the workgroup integrate the same group g of 16 rows (NetRegsTwin)
+  [[maybe_unused]] const int part = TW ? (wave & 1) : 0;
+  using WRegs = std::conditional_t<TW, NetRegsTwin<HP, MD, KS_, KSH_>, NetRegs<HP, MD, KS_, KSH_, L1M>>;
+  WRegs Wx, Wv;
   if (!P.hmc) {
-    Wx.load(Lx, lane);
-    Wv.load(Lv, lane);
+    if constexpr (TW) {
+      Wx.load(Lx, lane, part);
+      Wv.load(Lv, lane, part);
+    } else {
+      Wx.load(Lx, lane);
+      Wv.load(Lv, lane);
+    }
   }
   float* scr = scr_all + wave * 16 * V::NTH * 16;
+  [[maybe_unused]] f32x4s* xch = reinterpret_cast<f32x4s*>(scr_all + (kSmallThreads / 64) * 16 * V::NTH * 16) +
+                                 (wave >> 1) * 4 * V::NTH * 64;          // [group][2 parities][2 parts][NTH][64]
+  [[maybe_unused]] int ncall = 0;
   const bool prop = a.prop_B > 0;
-  const int64_t gw = (int64_t)blockIdx.x * (kSmallThreads / 64) + wave;
+  const int64_t gw = TW ? (int64_t)blockIdx.x * (kSmallThreads / 128) + (wave >> 1)
+                        : (int64_t)blockIdx.x * (kSmallThreads / 64) + wave;
   // trajectory mode: row r of [rows]; propose mode: chain r, direction (lane & 15) >> 3
   const int64_t r = prop ? gw * 8 + (lane & 7) : gw * 16 + (lane & 15);
   const bool live = r < (prop ? a.prop_B : a.rows);
@@ -499,7 +640,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
             const float k = d < dim ? (keep_is_m ? m[d] : 1.f - m[d]) : 1.f;
             bin[d] = k * x[d];
           }
-          if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lx, Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, S, T, Q, st);
+          if (!P.hmc) {
+            if constexpr (TW) net_eval_twin<HP, MD, KS_, KSH_>(Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, part, xch, ncall++ & 1, S, T, Q);
+            else net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lx, Wx, dim, P.xnet.q_tanh, v, bin, tc, ts, lane, S, T, Q, st);
+          }
           [[maybe_unused]] const unsigned long long tu = ST_NOW();
 #pragma unroll
           for (int d = 0; d < MD; ++d) {
@@ -520,7 +664,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
         }
         target(x, &E1, g);
       }
-      if (!P.hmc) net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lv, Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, S, T, Q, st);
+      if (!P.hmc) {
+        if constexpr (TW) net_eval_twin<HP, MD, KS_, KSH_>(Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, part, xch, ncall++ & 1, S, T, Q);
+        else net_eval_mfma<HP, MD, KS_, KSH_, L1M>(Lv, Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, S, T, Q, st);
+      }
       [[maybe_unused]] const unsigned long long tu2 = ST_NOW();
 #pragma unroll
       for (int d = 0; d < MD; ++d) {
@@ -539,11 +686,12 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
     }
   }
 #ifdef L2HMC_STAMPS
-  if (a.stamps && lane == 0) {
+  if (a.stamps && lane == 0 && part == 0) {
     st[6] = ST_NOW() - st_begin;
     for (int i = 0; i < 8; ++i) a.stamps[gw * 8 + i] = st[i];
   }
 #endif
+  if (TW && part) return;             // both waves of a group hold the same state: the first one finishes (no barrier follows)
   target(x, &E1, g);
   float kin1 = 0.f;
 #pragma unroll
@@ -598,17 +746,18 @@ template <int HP, int MD, int KS_, int KSH_>
 static size_t small_mfma_lds(int dim, int K, int N) {
   return sizeof(float) * (2 * (size_t)MfmaNet<HP, MD, KS_, KSH_>::size + target_view(dim, K).size + ((N * dim + 3) & ~3) +
                           (size_t)((2 * N + 3) & ~3) +
-                          (size_t)(kSmallThreads / 64) * 16 * MfmaNet<HP, MD, KS_, KSH_>::NTH * 16);
+                          (size_t)(kSmallThreads / 64) * 16 * MfmaNet<HP, MD, KS_, KSH_>::NTH * 16 +
+                          (size_t)(kSmallThreads / 128) * 4 * MfmaNet<HP, MD, KS_, KSH_>::NTH * 64 * 4);   // twin exchange patches
 }
 
-template <int HP, int MD, int KS_, int KSH_, bool L1M>
+template <int HP, int MD, int KS_, int KSH_, bool L1M, bool TW = false>
 static int launch_small_mfma_form(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
   const l2hmc_small_plan& P = a.plan;
   const size_t lds = small_mfma_lds<HP, MD, KS_, KSH_>(P.x_dim, P.target.K, P.trajectory_length);
   L2HMC_REQUIRE(lds <= 160 * 1024, "small_trajectory: LDS image %zu B too large", lds);
   static DeviceOnce attr_once;   // dynamic LDS beyond 64 KiB needs the opt-in (host-side, not a stream op)
   if (attr_once.pending()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M, TW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
@@ -616,21 +765,32 @@ static int launch_small_mfma_form(const SmallTrajArgs& a, dim3 grid, hipStream_t
 #ifdef L2HMC_STAMPS
   SmallTrajArgs b = a;
   b.stamps = g_stamp_cls == 7 ? g_stamp_buf : nullptr;
-  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>), grid, dim3(kSmallThreads), lds, st, b);
+  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M, TW>), grid, dim3(kSmallThreads), lds, st, b);
 #else
-  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M>), grid, dim3(kSmallThreads), lds, st, a);
+  hipLaunchKernelGGL((small_traj_mfma_kernel<HP, MD, KS_, KSH_, L1M, TW>), grid, dim3(kSmallThreads), lds, st, a);
 #endif
   prof_after(kProfSmall, st);
   L2HMC_CHECK_LAUNCH("small_trajectory");
   return L2HMC_OK;
 }
 
-// first layer on the matrix pipe while every wave has a SIMD to itself (<= 1024 waves of 16 chains), on the VALU for
-// larger batches; l2hmc_small_plan::first_layer_form forces one form (they agree to rounding: tests)
+// Three forms, chosen by the number of 16-row groups (l2hmc_small_plan::first_layer_form forces one; they walk sums in
+// different groupings and agree to rounding: tests):
+//   3  twin: two waves per group, every wave with a SIMD to itself (<= 512 groups on 1024 SIMDs; 64-unit instances)
+//   1  first layer on the matrix pipe, one wave per group (<= 1024 groups)
+//   2  first layer on the VALU: chip-filling batches
 template <int HP, int MD, int KS_, int KSH_>
 static int launch_small_mfma(const SmallTrajArgs& a, dim3 grid, hipStream_t st) {
   const int force = a.plan.first_layer_form;
-  const bool l1m = force ? force == 1 : ceil_div(a.rows, 16) <= 1024;
+  const int64_t groups = ceil_div(a.rows, 16);
+  constexpr bool can_twin = HP == 64;
+  if constexpr (can_twin) {
+    if (force == 3 || (force == 0 && groups <= 512)) {
+      const dim3 g2((unsigned)ceil_div(groups, kSmallThreads / 128));
+      return launch_small_mfma_form<HP, MD, KS_, KSH_, true, true>(a, g2, st);
+    }
+  }
+  const bool l1m = (force == 1 || force == 3) ? true : force == 2 ? false : groups <= 1024;
   return l1m ? launch_small_mfma_form<HP, MD, KS_, KSH_, true>(a, grid, st)
              : launch_small_mfma_form<HP, MD, KS_, KSH_, false>(a, grid, st);
 }
@@ -697,8 +857,9 @@ static int small_launch(const l2hmc_small_plan* plan, SmallTrajArgs a, l2hmc_str
   const int dim = plan->x_dim, H = plan->num_nodes, N = plan->trajectory_length;
   L2HMC_REQUIRE(dim == plan->target.dim, "small_trajectory: x_dim=%d != target dim=%d", dim, plan->target.dim);
   L2HMC_REQUIRE(N > 0 && plan->masks != nullptr, "small_trajectory: bad trajectory_length / masks");
-  L2HMC_REQUIRE(plan->first_layer_form >= 0 && plan->first_layer_form <= 2,
-                "small_trajectory: first_layer_form=%d (0 by batch size, 1 matrix pipe, 2 VALU)", plan->first_layer_form);
+  L2HMC_REQUIRE(plan->first_layer_form >= 0 && plan->first_layer_form <= 3,
+                "small_trajectory: first_layer_form=%d (0 by batch size, 1 matrix pipe, 2 VALU, 3 two waves per group)",
+                plan->first_layer_form);
   const int64_t rows = a.rows;
   if (!plan->hmc) {
     L2HMC_REQUIRE(H > 0 && H <= 64, "small_trajectory: num_nodes=%d unsupported (1..64)", H);

@@ -723,7 +723,8 @@ def test_both_first_layer_forms_of_the_toy_kernel_agree(la, name, B):
     v = torch.as_tensor(rng.standard_normal((B, 2)), dtype=torch.float32, device="cuda")
     outs = {}
     try:
-        for form in (1, 2, 1):                  # 1 = matrix pipe, 2 = VALU (l2hmc_small_plan::first_layer_form)
+        # 1 = first layer on the matrix pipe, 2 = on the VALU, 3 = two waves per group (l2hmc_small_plan::first_layer_form)
+        for form in ((1, 2, 3, 1, 3) if name.startswith("mog") else (1, 2, 1)):
             dyn.first_layer_form = form
             dyn._draws = 20
             Lx, _, px, mh = la.propose(x, dyn, do_mh_step=False)
@@ -739,6 +740,10 @@ def test_both_first_layer_forms_of_the_toy_kernel_agree(la, name, B):
     print("toy kernel, matrix-pipe vs VALU first layer:", " ".join(f"{e:.1e}" for e in errs))
     # two fp32 summation orders of the same N-step trajectory (measured: profiles/r03_gate_envelope.txt)
     assert max(errs) < FORMS_TOL, errs
+    if 3 in outs:
+        errs3 = [H.relerr(np_(a), np_(b)) for a, b in zip(outs[1], outs[3])]
+        print("toy kernel, one wave vs two waves per group:", " ".join(f"{e:.1e}" for e in errs3))
+        assert max(errs3) < FORMS_TOL, errs3
     assert float(outs[1][1].mean()) > 0.01          # not a trivially rejected batch
 
 
