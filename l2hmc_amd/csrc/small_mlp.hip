@@ -249,12 +249,15 @@ __device__ __forceinline__ void net_eval_twin(const NetRegsTwin<HP, MD, KS_, KSH
   using V = MfmaNet<HP, MD, KS_, KSH_>;
   constexpr int NT = V::NT, NTH = V::NTH, KS1 = V::KS1, K2 = V::KSH, KO = 8;
   const int q = lane >> 4, r = lane & 15;
-  // ---- layer 1, whole (both waves need every hidden unit as k of layer 2)
+  // ---- layer 1, whole (both waves need every hidden unit as k of layer 2).  The LAST k-step -- [.., cos t, sin t, 1, 0]:
+  // time term and bias -- goes first: it depends on nothing the caller computes right before the call (the target's
+  // gradient for the momentum network), so its matrix instructions can issue under that arithmetic
   f32x4s acc[NT];
 #pragma unroll
   for (int to = 0; to < NT; ++to) acc[to] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < KS1; ++s) {
+  for (int s0 = 0; s0 < KS1; ++s0) {
+    const int s = (s0 + KS1 - 1) % KS1;           // KS1 - 1, 0, 1, ...
     float e4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -485,6 +488,7 @@ struct TargetRegs {
       }
     }
   }
+  // E == nullptr: gradient only (the energy's logf is needed at the two ends of a trajectory, not inside it)
   __device__ __forceinline__ void eval(int dim, int K, int is_gaussian, float inv_temp, const float (&x)[MD], float* E,
                                        float (&g)[MD]) const {
     float V[KM];
@@ -527,8 +531,10 @@ struct TargetRegs {
         }
       }
     }
-    const float e = is_gaussian ? -V[0] : -(vmax + logf(sw));
-    *E = e * inv_temp;
+    if (E) {
+      const float e = is_gaussian ? -V[0] : -(vmax + logf(sw));
+      *E = e * inv_temp;
+    }
 #pragma unroll
     for (int d = 0; d < MD; ++d) g[d] = g[d] / sw * inv_temp;
   }
@@ -609,10 +615,11 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
   if (treg) tregs.load(Lt, dim, K);
   auto target = [&](const float (&xx)[MD], float* E, float (&gg)[MD]) {
     [[maybe_unused]] const unsigned long long tt = ST_NOW();
+    float dummy;
     if (treg) tregs.eval(dim, K, isg, inv_temp, xx, E, gg);
-    else energy_grad<MD>(Lt, dim, K, isg, inv_temp, xx, E, gg);
+    else energy_grad<MD>(Lt, dim, K, isg, inv_temp, xx, E ? E : &dummy, gg);
 #ifdef L2HMC_STAMPS
-    asm volatile("" :: "v"(*E), "v"(gg[0]));
+    asm volatile("" :: "v"(gg[0]));
 #endif
     ST_ADD(4, tt);
   };
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_traj_mfma_kernel(SmallTra
 #endif
           ST_ADD(5, tu);
         }
-        target(x, &E1, g);
+        target(x, nullptr, g);         // (the energy itself is needed only after the last step: below)
       }
       if (!P.hmc) {
         if constexpr (TW) net_eval_twin<HP, MD, KS_, KSH_>(Wv, dim, P.vnet.q_tanh, x, g, tc, ts, lane, part, xch, ncall++ & 1, S, T, Q);
