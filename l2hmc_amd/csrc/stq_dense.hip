@@ -824,7 +824,8 @@ int launch_gemm_relu(GemmReluArgs& a, hipStream_t stream) {
                       (a.cmask_f && (!aligned16(a.cmask_f) || !aligned16(a.cmask_b)));
   L2HMC_REQUIRE(((!a.acc_in && !a.acc_out) || (!ragged && a.kind == 0)) &&
                     (!a.acc_in || (a.k_begin % BK == 0 && a.k_begin > 0 && a.k_begin < a.K)) &&
-                    (!a.acc_out || (a.k_dump % BK == 0 && a.k_dump > 0 && a.k_dump <= a.K)),
+                    (!a.acc_out || (a.k_dump % BK == 0 && a.k_dump > 0 && a.k_dump <= a.K)) &&
+                    (!(a.acc_in && a.acc_out) || a.k_dump > a.k_begin),       // (a dump at or before the resume point would be skipped)
                 "gemm: a kept first-layer product needs tile-aligned widths (k_begin=%d, k_dump=%d, K=%d)", a.k_begin,
                 a.k_dump, a.K);
   if (ragged) {
