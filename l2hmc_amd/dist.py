@@ -38,10 +38,12 @@ class StepStats:
     """Per-step fused scalar buffer [sum p_accept, sum |dQ|, n_chains], combined over the ranks by an asynchronous
     all-reduce(SUM) on a side stream so the next trajectory does not wait for it.  `reduce_every` steps share ONE
     all-reduce of their stacked buffers [k, 3] (every step's global sums are the same numbers as with one collective
-    per step, k - 1 steps later): the whole-step kernel owns every CU with a full register file, so a collective
-    kernel between two steps displaces a workgroup of the next one -- measured 21 us per step at the headline shape
-    with one all-reduce per step (1.3 % of a step, profiles/r04_bench_world1_rccl.json), nothing measurable with 16
-    steps per all-reduce.  reduce_every = 1 restores one collective per step."""
+    per step, k - 1 steps later).  Measured with a one-rank RCCL group at the headline shape
+    (profiles/r04_world1_rccl_kernel_trace.txt, bench.py: config.world1_rccl): the event that hands a step's sums to the
+    side stream drains the launch queue between two step kernels -- a 17.6 us gap, 1.2 % of a step, with one all-reduce
+    per step; one such gap per 16 steps (0.3 %) with the grouping.  At N > 1 the collective's own kernel, which has to
+    find a CU among workgroups that hold full register files, is divided by 16 too.  reduce_every = 1 restores one
+    collective per step."""
 
     def __init__(self, device, dist=None, reduce_every=16):
         self.device = torch.device(device)
