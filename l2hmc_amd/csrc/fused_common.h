@@ -56,11 +56,15 @@ __device__ __forceinline__ f32x4 lane_frag(const WSection& ws, unsigned frag_ind
   return buf_load16(ws, (threadIdx.x & 63u) * 16u, frag_index * 1024u);
 }
 
-// wp (below): the WAVE's section base, wave-uniform (kernel argument + readfirstlane'd wave number)
-template <int NT>
-__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const WSection& ws, int kc) {
+// wp (below): the section base of the image's wave, wave-uniform (kernel argument + readfirstlane'd wave number).
+// A wave's tile t of k-chunk kc is fragment kc * NTI + toff + t * TS of that section: NTI = tiles per chunk in the IMAGE.
+// A kernel with as many waves as the image was packed for walks its own section (NTI = NT, toff = 0, TS = 1); a kernel
+// with twice the waves shares a section between two waves (the 8-wave sampling instance on the 4-wave image:
+// layers 1 / 2 toff = 4 (wave & 1), the heads -- tiles [S | T | Q] x 2 -- toff = wave & 1, TS = 2).
+template <int NT, int NTI = NT, int TS = 1>
+__device__ __forceinline__ void load_frags(f32x4 (&b)[NT], const WSection& ws, int kc, int toff = 0) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NT + t));
+  for (int t = 0; t < NT; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NTI + toff + t * TS));
 }
 
 // Ring of B fragments, DEPTH slots of NT fragments; chunk k of the walk lives in slot k % DEPTH and every slot is
@@ -81,23 +85,23 @@ struct BRing {
   f32x4 b[DEPTH][NT];
 };
 
-template <int NT, int T0, int T1>
-__device__ __forceinline__ void load_group(f32x4 (&b)[NT], const WSection& ws, int kc) {
+template <int NT, int T0, int T1, int NTI = NT, int TS = 1>
+__device__ __forceinline__ void load_group(f32x4 (&b)[NT], const WSection& ws, int kc, int toff = 0) {
 #pragma unroll
-  for (int t = T0; t < T1; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NT + t));
+  for (int t = T0; t < T1; ++t) b[t] = lane_frag(ws, (unsigned)(kc * NTI + toff + t * TS));
 }
 
 // rev: the layer's k-chunks are walked from the last to the first (NKC chunks in all).  A network's image is
 // streamed in alternating directions on its consecutive calls, so the part of it that the previous call left in L2
 // -- its most recently touched end -- is what the next call asks for first.
 // Primes chunks 0 .. DEPTH - 1 of the walk except the last slot's second tile group, which the first block requests.
-template <int NT, int DEPTH>
+template <int NT, int DEPTH, int NTI = NT, int TS = 1>
 __device__ __forceinline__ void ring_prime(BRing<NT, DEPTH>& R, const float* __restrict__ wp, bool rev = false,
-                                           int nkc = 0) {
+                                           int nkc = 0, int toff = 0) {
   const WSection ws = wsection(wp);
 #pragma unroll
-  for (int s = 0; s < DEPTH - 1; ++s) load_frags<NT>(R.b[s], ws, rev ? nkc - 1 - s : s);
-  load_group<NT, 0, (NT + 1) / 2>(R.b[DEPTH - 1], ws, rev ? nkc - DEPTH : DEPTH - 1);
+  for (int s = 0; s < DEPTH - 1; ++s) load_frags<NT, NTI, TS>(R.b[s], ws, rev ? nkc - 1 - s : s, toff);
+  load_group<NT, 0, (NT + 1) / 2, NTI, TS>(R.b[DEPTH - 1], ws, rev ? nkc - DEPTH : DEPTH - 1, toff);
 }
 
 // Half a block: acc[t] += cur[t] (x) a over the chunk's four k-steps for the tiles [T0, T1), e-major (every
@@ -114,31 +118,10 @@ __device__ __forceinline__ void sched_mfma_load_pipeline() {
   }
 }
 
-template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0>
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0, int NTI = NT, int TS = 1>
 __device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
-                                                 f32x4 (&acc)[NT], const WSection& wp, int kc) {
+                                                 f32x4 (&acc)[NT], const WSection& wp, int kc, int toff = 0) {
   constexpr int G = T1 - T0, NLD = L1 - L0;
-#ifdef L2HMC_MFMA_ASM
-  // experiment: accumulate IN PLACE (vDst == SrcC) through inline asm, order pinned by sched_barrier
-#pragma unroll
-  for (int i = 0; i < 4 * G; ++i) {
-    const int e = i / G, t = T0 + i % G;
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(cur[t][e]), "v"(a[e]));
-    if ((i & 3) == 3) {
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (LOAD) {
-        if ((i >> 2) < NLD)
-          dst[L0 + (i >> 2)] = lane_frag(wp, (unsigned)(kc * NT + L0 + (i >> 2)));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if constexpr (LOAD) {
-#pragma unroll
-    for (int j = G; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
-  }
-  return;
-#endif
 #pragma unroll
   for (int i = 0; i < 4 * G; ++i) {
     const int e = i / G, t = T0 + i % G;
@@ -146,7 +129,7 @@ __device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cu
   }
   if constexpr (LOAD) {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NTI + toff + (L0 + j) * TS));
   }
   // the order the scheduler must emit: the NDS LDS reads of the NEXT block's activation fragment first (left to float
   // they sink to the block's end and the next block waits out the whole LDS latency), then four MFMAs, one load, ...
@@ -156,9 +139,9 @@ __device__ __forceinline__ void mfma_half_stream(const f32x4 a, const f32x4 (&cu
 
 // wp: this wave's section base (wave-uniform).  afrag(kc) returns the lane's A fragment of chunk kc
 // (the fragment of the next chunk is fetched from LDS while the current block's MFMAs issue).
-template <int NT, int NKC, int DEPTH, typename AF>
+template <int NT, int NKC, int DEPTH, int NTI = NT, int TS = 1, typename AF>
 __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* __restrict__ wbase, AF afrag,
-                                             f32x4 (&acc)[NT], bool rev = false) {
+                                             f32x4 (&acc)[NT], bool rev = false, int toff = 0) {
   const WSection wp = wsection(wbase);
   static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
   constexpr int G = (NT + 1) / 2;                              // tiles [0, G) and [G, NT)
@@ -176,8 +159,9 @@ __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* _
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
       const f32x4 a1 = afrag(km(kc + s + 1));
-      mfma_half_stream<NT, 0, G, G, NT, true, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(kc + s + DEPTH - 1));
-      mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(kc + s + DEPTH));
+      mfma_half_stream<NT, 0, G, G, NT, true, 1, NTI, TS>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp,
+                                                          km(kc + s + DEPTH - 1), toff);
+      mfma_half_stream<NT, G, NT, 0, G, true, 0, NTI, TS>(a0, R.b[s], R.b[s], acc, wp, km(kc + s + DEPTH), toff);
       a0 = a1;
     }
   }
@@ -186,11 +170,12 @@ __device__ __forceinline__ void stream_layer(BRing<NT, DEPTH>& R, const float* _
     const int s = (k - MAIN) % DEPTH;
     const f32x4 a1 = afrag(km(k + 1 < NKC ? k + 1 : NKC - 1));
     if (k + DEPTH - 1 < NKC)
-      mfma_half_stream<NT, 0, G, G, NT, true, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, km(k + DEPTH - 1));
+      mfma_half_stream<NT, 0, G, G, NT, true, 1, NTI, TS>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp,
+                                                          km(k + DEPTH - 1), toff);
     else
       mfma_half_stream<NT, 0, G, G, NT, false, 1>(a0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc, wp, 0);
     if (k + DEPTH < NKC)
-      mfma_half_stream<NT, G, NT, 0, G, true>(a0, R.b[s], R.b[s], acc, wp, km(k + DEPTH));
+      mfma_half_stream<NT, G, NT, 0, G, true, 0, NTI, TS>(a0, R.b[s], R.b[s], acc, wp, km(k + DEPTH), toff);
     else
       mfma_half_stream<NT, G, NT, 0, G, false>(a0, R.b[s], R.b[s], acc, wp, 0);
     a0 = a1;

@@ -32,19 +32,32 @@ namespace l2hmc {
 
 // D = x_dim, H = hidden width, KA = width of each first-layer input (x_dim for GenericNet; the flattened conv
 // features for ConvNet3D), CONV = the two inputs go through the conv front-end first (8x8 lattice, F = 8).
-template <int D, int H, int KA = D, bool CONV = false>
+template <int D, int H, int KA = D, bool CONV = false, bool TAPE = false>
 struct FusedCfg {
-  // ConvNet3D plans run TWO waves per SIMD: their VALU conv stage is latency-bound at one (measured 0.987 -> 0.883 ms
-  // per step), while the GenericNet kernel, all MFMA streaming, is faster with one (1.655 against 1.745 ms)
-  static constexpr int WAVES = CONV ? 2 * kFWaves : kFWaves;
+  // Waves per workgroup.  ConvNet3D plans run TWO waves per SIMD: their VALU conv stage is latency-bound at one
+  // (measured 0.987 -> 0.883 ms per step).  The GenericNet kernel used to be faster with one wave per SIMD (rounds 1-3:
+  // 1.655 against 1.745 ms); with the weight stream of round 4 (buffer loads, pinned interleave) two win -- one wave's
+  // epilogues and barriers lie under the other's matrix instructions: 1.431 -> 1.38 ms per step.  The TAPED forward of
+  // the training path stays at one wave per SIMD: its relu-gate words are laid out in the lane order the 4-wave reverse
+  // kernel reads (fused_train.hip).
+  // IMGW: waves the packed weight image is laid out for (pack_fused_kernel).  The 8-wave GenericNet instance reads the
+  // SAME 4-wave image as the taped forward and the 32-row form: two waves share a section (fused_common.h: load_frags).
+  static constexpr int IMGW = CONV ? 2 * kFWaves : kFWaves;
+  static constexpr int WAVES = (CONV || TAPE) ? IMGW : 2 * IMGW;
+  static constexpr int RW = WAVES / IMGW;      // waves per image section
   static constexpr int THREADS = 64 * WAVES;   // wave w owns output columns [w*N/WAVES, (w+1)*N/WAVES)
-  static constexpr int TPC = THREADS / kFM;    // threads per chain in the chain-local passes
+  // threads per chain in the chain-local passes (force, kinetic energy, observables): their sums are part of the
+  // result's bits, so the GenericNet instances keep 16 whatever their wave count (the other threads idle there)
+  static constexpr int TPC = CONV ? THREADS / kFM : 16;
   static constexpr int SX = D + 8;             // LDS row stride of x / v / second-input rows
   static constexpr int SA = KA + 8;            // LDS row stride of the conv feature rows
   static constexpr int SH = H + 8;             // LDS row stride of h1 / h2
   static constexpr int NT1 = H / (16 * WAVES);     // 16-column tiles per wave, layers 1 and 2
   static constexpr int NTH = D / (16 * WAVES);     // tiles per wave per head
+  static constexpr int NTI1 = H / (16 * IMGW);     // ... and per image section (= NT1, NTH unless two waves share it)
+  static constexpr int NTIH = D / (16 * IMGW);
   static_assert(NT1 >= 1 && NT1 <= 8 && NTH >= 1, "every wave needs at least one tile per layer");
+  static_assert(RW == 1 || NTH == 1, "a shared heads section is walked with one tile per head and wave");
   static constexpr int KC1 = 2 * KA / 16;      // k-chunks (16 k each), layer 1
   static constexpr int KC2 = H / 16;           // k-chunks, layers 2 and heads
   static constexpr size_t P1 = (size_t)2 * KA * H;  // packed floats per section
@@ -59,8 +72,8 @@ struct FusedCfg {
   static constexpr int CP1 = (CL / 2 + 1) * (CL / 2 + 1) * CF;              // pooled conv1 map, zero halo
   static constexpr int CONV_FLOATS = CONV ? 2 * kFM * SA + 4 * CW + kFM * (CXIN + CP1) : 0;
   static constexpr int LDS_FLOATS = 3 * kFM * SX + 2 * kFM * SH + 2 * NC + kFM * (D / 2 + 4) /*sinP*/ +
-                                    2 * D /*masks*/ + WAVES * kFM /*ldw*/ + kFM /*dir*/ + 8 * kFM /*step mode*/ +
-                                    CONV_FLOATS;
+                                    2 * D /*masks*/ + WAVES * kFM /*ldw*/ + (RW > 1 ? IMGW * 64 : 0) /*ldx*/ + kFM /*dir*/ +
+                                    8 * kFM /*step mode*/ + CONV_FLOATS;
 };
 
 // ---------------------------------------------------------------------------
@@ -127,10 +140,12 @@ extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; 
 
 // TAPE: training instantiation (GenericNet plans) that also writes the per-call tape of train.hip
 template <int D, int H, int KA, bool CONV, bool TAPE = false>
-__global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_traj_fused_kernel(FusedArgs p) {
-  using Cfg = FusedCfg<D, H, KA, CONV>;
+__global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gauge_traj_fused_kernel(FusedArgs p) {
+  using Cfg = FusedCfg<D, H, KA, CONV, TAPE>;
   constexpr int kFWaves = Cfg::WAVES, kFThreads = Cfg::THREADS, kTPC = Cfg::TPC;   // this instance's geometry
   constexpr int SX = Cfg::SX, SH = Cfg::SH, SA = Cfg::SA, NT1 = Cfg::NT1, NTH = Cfg::NTH;
+  constexpr int RW = Cfg::RW, IMGW = Cfg::IMGW, NTI1 = Cfg::NTI1, NTIH = Cfg::NTIH;
+  constexpr int TSH = RW > 1 ? NTIH : 1;       // tile stride of a wave's heads fragments in a shared section
   constexpr int sites = D / 2;
   constexpr int SP = sites + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,8 +158,10 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   float* cv = cx + Cfg::NC;                // VNet constants [NC]
   float* sp = cv + Cfg::NC;                // [16][SP] sin P
   float* skm = sp + kFM * SP;              // [2][D]  masks of this step: forward row, backward row
-  float* ldw = skm + 2 * D;                // [waves][16] log-det partial sums per wave
-  int* sdir = reinterpret_cast<int*>(ldw + kFWaves * kFM);   // [16]
+  float* ldw = skm + 2 * D;                // [IMGW][16] log-det partial sums per image wave; behind them (RW > 1 only)
+                                           // [IMGW][64] the lane sums an even wave hands to its odd partner
+  float* ldx = ldw + IMGW * kFM;
+  int* sdir = reinterpret_cast<int*>(ldw + kFWaves * kFM + (RW > 1 ? IMGW * 64 : 0));   // [16]
   float* stp = reinterpret_cast<float*>(sdir + kFM);  // step mode: coin[16] u[16] p_row[16] obs[16][4]
   // ConvNet3D front-end state (CONV only; zero-sized otherwise)
   float* fa = stp + 8 * kFM;                          // [16][SA] features of the first input
@@ -266,13 +283,17 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     else if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
     sdir[tid] = d;
   }
-  if (tid < kFWaves * kFM) ldw[tid] = 0.f;
+  if (tid < IMGW * kFM) ldw[tid] = 0.f;
   __syncthreads();
 
   const int dirl = sdir[r];           // direction of the row this lane owns in a C fragment (fused_common.h)
 
   // ---- chain-local passes: kTPC consecutive threads per chain ------------------
-  const int fc = tid / kTPC, fl = tid % kTPC;      // chain, lane-in-chain
+  // (GenericNet instances: kTPC = 16 whatever the wave count; the threads beyond 16 chains x 16 walk empty loops and
+  //  take part in the barriers only)
+  const bool own = tid < kFM * kTPC;
+  const int fc = own ? tid / kTPC : 0, fl = tid % kTPC;      // chain, lane-in-chain
+  const int sites_l = own ? sites : 0, D_l = own ? D : 0;    // loop bounds of the chain-local passes
   auto chain_sum = [&](float v) {
 #pragma unroll
     for (int off = kTPC / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -284,7 +305,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   auto force_pass = [&]() -> float {
     const float* xc = xs + fc * SX;
     float act = 0.f;
-    for (int s = fl; s < sites; s += kTPC) {
+    for (int s = fl; s < sites_l; s += kTPC) {
       const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
       const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
       const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
@@ -297,7 +318,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     __syncthreads();
     float* gc = gs + fc * SX;
     const float* spc = sp + fc * SP;
-    for (int s = fl; s < sites; s += kTPC) {
+    for (int s = fl; s < sites_l; s += kTPC) {
       const int i = s >> xsh, j = s & (X - 1);            // X is a power of two (T * X = 64)
       const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
       const float sP = spc[s];
@@ -310,7 +331,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   auto kinetic_pass = [&]() -> float {
     const float* vc = vs + fc * SX;
     float k = 0.f;
-    for (int d = fl; d < D; d += kTPC) k += vc[d] * vc[d];
+    for (int d = fl; d < D_l; d += kTPC) k += vc[d] * vc[d];
     return 0.5f * chain_sum(k);
   };
 
@@ -472,9 +493,12 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       }
     };
     const int wv = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: the weight loads' base stays in SGPRs
-    const float* wp1 = pk + (size_t)wv * Cfg::KC1 * NT1 * 256;
-    const float* wp2 = pk + Cfg::P1 + (size_t)wv * Cfg::KC2 * NT1 * 256;
-    const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wv * Cfg::KC2 * 3 * NTH * 256;
+    const int wimg = wv / RW, wsub = wv - wimg * RW;          // image section, and this wave's share of it
+    const float* wp1 = pk + (size_t)wimg * Cfg::KC1 * NTI1 * 256;
+    const float* wp2 = pk + Cfg::P1 + (size_t)wimg * Cfg::KC2 * NTI1 * 256;
+    const float* wph = pk + Cfg::P1 + Cfg::P2 + (size_t)wimg * Cfg::KC2 * 3 * NTIH * 256;
+    const int to1 = wsub * NT1, toh = wsub * NTH;             // first tile of this wave in a chunk of the section
+    [[maybe_unused]] float ld_k[4] = {0.f, 0.f, 0.f, 0.f}, ld_s[4] = {0.f, 0.f, 0.f, 0.f};   // (RW > 1: the odd wave's log-det terms)
 #ifndef L2HMC_DP1                                 // (A/B builds: tools/build_variant.sh)
 #define L2HMC_DP1 3
 #define L2HMC_DP2 3
@@ -515,32 +539,32 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
         for (int t = 0; t < NT1; ++t) acc[t] = keep_v[t];
       } else {
         BRing<NT1, DP1> RA, RB;
-        const float* wpb = wp1 + (size_t)KH * NT1 * 256;
-        ring_prime<NT1, DP1>(RB, wpb);          // both halves' first fragments are requested up front
+        const float* wpb = wp1 + (size_t)KH * NTI1 * 256;
+        ring_prime<NT1, DP1, NTI1>(RB, wpb, false, 0, to1);          // both halves' first fragments are requested up front
         if (l1 == 4) {
 #pragma unroll
           for (int t = 0; t < NT1; ++t) acc[t] = keep_x[t];
         } else {
-          ring_prime<NT1, DP1>(RA, wp1);
+          ring_prime<NT1, DP1, NTI1>(RA, wp1, false, 0, to1);
 #pragma unroll
           for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
           const float* a1 = src1 + r * s1 + q * 4;
-          stream_layer<NT1, KH, DP1>(
-              RA, wp1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a1 + kc * 16); }, acc);
+          stream_layer<NT1, KH, DP1, NTI1>(
+              RA, wp1, [&](int kc) { return *reinterpret_cast<const f32x4*>(a1 + kc * 16); }, acc, false, to1);
           if (l1 == 3) {
 #pragma unroll
             for (int t = 0; t < NT1; ++t) keep_x[t] = acc[t];
           }
         }
         const float* a2 = src2 + r * s1 + q * 4;
-        stream_layer<NT1, KH, DP1>(
-            RB, wpb, [&](int kc) { return *reinterpret_cast<const f32x4*>(a2 + kc * 16); }, acc);
+        stream_layer<NT1, KH, DP1, NTI1>(
+            RB, wpb, [&](int kc) { return *reinterpret_cast<const f32x4*>(a2 + kc * 16); }, acc, false, to1);
         if (l1 == 1) {
 #pragma unroll
           for (int t = 0; t < NT1; ++t) keep_v[t] = acc[t];
         }
       }
-      ring_prime<NT1, DP2>(R2, wp2, zig, Cfg::KC2);      // layer-2 weights start flowing under the epilogue + barrier
+      ring_prime<NT1, DP2, NTI1>(R2, wp2, zig, Cfg::KC2, to1);      // layer-2 weights start flowing under the epilogue + barrier
       FT_ADD(0, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -574,9 +598,9 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* a = h1 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
-      stream_layer<NT1, Cfg::KC2, DP2>(
-          R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig);
-      ring_prime<3 * NTH, DPH>(R3, wph, zig, Cfg::KC2);
+      stream_layer<NT1, Cfg::KC2, DP2, NTI1>(
+          R2, wp2, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig, to1);
+      ring_prime<3 * NTH, DPH, 3 * NTIH, TSH>(R3, wph, zig, Cfg::KC2, toh);
       FT_ADD(1, t0);
       t0 = FT_NOW();
       [[maybe_unused]] unsigned gmask = 0;
@@ -608,8 +632,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       for (int t = 0; t < 3 * NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* a = h2 + r * SH + q * 4;
       [[maybe_unused]] unsigned long long t0 = FT_NOW();
-      stream_layer<3 * NTH, Cfg::KC2, DPH>(
-          R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig);
+      stream_layer<3 * NTH, Cfg::KC2, DPH, 3 * NTIH, TSH>(
+          R3, wph, [&](int kc) { return *reinterpret_cast<const f32x4*>(a + kc * 16); }, acc, zig, toh);
       FT_ADD(2, t0);
       t0 = FT_NOW();
       float ld = 0.f;                       // this lane's share of row r's log-det
@@ -657,6 +681,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
             const float es_ = fast_exp(s);
             vn[e] = d ? es_ * (v[e] + kick) : v[e] * es_ - kick;
             ld += s;
+            if constexpr (RW > 1) { ld_k[e] = 1.f; ld_s[e] = s; }
           }
           *reinterpret_cast<f32x4*>(vs + idx) = vn;
           // the next net call is the first position sub-update: its second input is keep (.) x
@@ -681,6 +706,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
             const float upd = d ? es_ * (x[e] - drift) : x[e] * es_ + drift;
             xn[e] = keep * x[e] + (1.f - keep) * upd;
             ld += (1.f - keep) * s;
+            if constexpr (RW > 1) { ld_k[e] = 1.f - keep; ld_s[e] = s; }
             kx[e] = (1.f - keep) * xn[e];
           }
           *reinterpret_cast<f32x4*>(xs + idx) = xn;
@@ -689,15 +715,32 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
         }
       }
       // row r's log-det share of this wave: lanes r, r + 16, r + 32, r + 48 (fixed order: bit-reproducible)
-      ld += __shfl_xor(ld, 16, 64);
-      ld += __shfl_xor(ld, 32, 64);
-      if (q == 0) ldw[wave * kFM + r] += ld;
+      if constexpr (RW == 1) {
+        ld += __shfl_xor(ld, 16, 64);
+        ld += __shfl_xor(ld, 32, 64);
+        if (q == 0) ldw[wave * kFM + r] += ld;
+      } else {
+        // Two waves share an image wave's columns.  The bits of the 4-wave forms are those of ONE chain of adds per
+        // lane over both waves' tiles, then the cross-lane steps: the even wave hands its lane sum over, the odd wave
+        // continues the chain with its own four terms behind the barrier below (ld_terms) and does the rest.
+        if (wsub == 0) ldx[wimg * 64 + lane] = ld;
+      }
       FT_ADD(5, t0);
     }
     {
       [[maybe_unused]] const unsigned long long tb = FT_NOW();
       __syncthreads();
       FT_ADD(6, tb);
+    }
+    if constexpr (RW > 1) {
+      if (wsub == 1) {
+        float ld = ldx[wimg * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ld += ld_k[e] * ld_s[e];      // (the same contracted multiply-add as the chain above)
+        ld += __shfl_xor(ld, 16, 64);
+        ld += __shfl_xor(ld, 32, 64);
+        if (q == 0) ldw[wimg * kFM + r] += ld;
+      }
     }
   };
 
@@ -737,10 +780,10 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
   const float act1 = force_pass();
   const float kin1 = kinetic_pass();
   if (STEPM) {
-    if (fl == 0) {
+    if (own && fl == 0) {
       float sld = 0.f;
 #pragma unroll
-      for (int w = 0; w < kFWaves; ++w) sld += ldw[w * kFM + fc];
+      for (int w = 0; w < IMGW; ++w) sld += ldw[w * kFM + fc];
       const double dh = (double)p.beta * ((double)act0 - (double)act1) + ((double)kin0 - (double)kin1) + (double)sld;
       spx[fc] = accept_from_delta(dh);
     }
@@ -789,7 +832,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     auto plaq_sums = [&](const float* xc, float& scos, float& sproj) {
       const float inv2pi = 0.15915494309189533577f;
       float a = 0.f, b = 0.f;
-      for (int st = fl; st < sites; st += kTPC) {
+      for (int st = fl; st < sites_l; st += kTPC) {
         const int i = st >> xsh, j = st & (X - 1);
         const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
         const float P = xc[2 * st] - xc[2 * st + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
@@ -804,7 +847,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     if (p.step_both) {
       float a, b;
       plaq_sums(fc < kFM / 2 ? gin + fc * SX : gout + (fc - kFM / 2) * SX, a, b);
-      if (fl == 0) {
+      if (own && fl == 0) {
         if (fc < kFM / 2) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; }
         else sobs[(fc - kFM / 2) * 4 + 2] = b;
       }
@@ -812,7 +855,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
       float a, b, c_, d_;
       plaq_sums(gin + fc * SX, a, b);
       plaq_sums(gout + fc * SX, c_, d_);
-      if (fl == 0) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; sobs[fc * 4 + 2] = d_; }
+      if (own && fl == 0) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; sobs[fc * 4 + 2] = d_; }
     }
     __syncthreads();
     const float inv2pi = 0.15915494309189533577f;
@@ -890,11 +933,11 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_tra
     }
     return;
   }
-  if (fl == 0 && fc < nrow) {
+  if (own && fl == 0 && fc < nrow) {
     float sld = 0.f;
 
 #pragma unroll
-    for (int w = 0; w < kFWaves; ++w) sld += ldw[w * kFM + fc];      // fixed order: bit-reproducible
+    for (int w = 0; w < IMGW; ++w) sld += ldw[w * kFM + fc];      // fixed order: bit-reproducible
     const int64_t rr = row0 + fc;
     if (p.logdet) p.logdet[rr] = p.logdet_accumulate ? p.logdet[rr] + sld : sld;
     if (p.p_accept) {
@@ -965,9 +1008,11 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
                             const FusedTape* tape_v) {
   const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   using CfgG = FusedCfg<128, 512, 128, false>;
+  using CfgGT = FusedCfg<128, 512, 128, false, true>;          // (taped: one wave per image wave)
   using CfgC = FusedCfg<128, 256, 64, true>;
   static DeviceOnce attr_once;
-  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : CfgG::LDS_FLOATS);
+  const bool tape = tape_x && tape_v;
+  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : tape ? CfgGT::LDS_FLOATS : CfgG::LDS_FLOATS);
   if (attr_once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -987,7 +1032,6 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   a.x0 = x0; a.v0 = v0; a.dir = dir; a.rows = rows; a.x_out = x_out; a.v_out = v_out;
   a.x_mod = x_mod; a.dir_split = dir_split;
   a.logdet = logdet; a.logdet_accumulate = logdet_accumulate; a.p_accept = p_accept;
-  const bool tape = tape_x && tape_v;
   if (tape) {
     L2HMC_REQUIRE(step_begin == 0, "fused trajectory: taping needs the whole trajectory");
     L2HMC_REQUIRE(!conv || (tape_x->feat && tape_v->feat), "fused trajectory: ConvNet3D taping needs the feature tape");
@@ -1000,7 +1044,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
     if (tape_once.pending()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
+                              (int)(sizeof(float) * CfgGT::LDS_FLOATS)) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 256, 64, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(float) * CfgC::LDS_FLOATS)) != hipSuccess) {
@@ -1027,7 +1071,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   else if (conv)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(CfgC::THREADS), lds, stream, a);
   else if (tape)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(CfgG::THREADS), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(CfgGT::THREADS), lds, stream, a);
   else
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(CfgG::THREADS), lds, stream, a);
   prof_after(kProfFused, stream);
@@ -1176,7 +1220,7 @@ extern "C" int l2hmc_dense_pack(const l2hmc_dense_net* net, float* packed, l2hmc
   L2HMC_REQUIRE(fused_net_supported(net), "dense_pack: shape (D=%d, H=%d, Ka=%d, Kb=%d) has no fused kernel",
                 net->D, net->H, net->Ka, net->Kb);
   L2HMC_REQUIRE(net->w1_t && net->wh_t && net->whd_t, "dense_pack: NULL weight pointer");
-  const int waves = fused_conv_net(net) ? FusedCfg<128, 256, 64, true>::WAVES : FusedCfg<128, 512, 128, false>::WAVES;
+  const int waves = fused_conv_net(net) ? FusedCfg<128, 256, 64, true>::IMGW : FusedCfg<128, 512, 128, false>::IMGW;
   hipLaunchKernelGGL(pack_fused_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *net, packed, waves);
   L2HMC_CHECK_LAUNCH("dense_pack");
   if (fused4_pack_floats(net))
