@@ -13,6 +13,10 @@
 // the flattened features go straight into the k-contiguous layout the dense trunk's first GEMM reads.
 // This stage is <20 % of the network's FLOPs and VALU-bound; filters are read with
 // the channel index on the lane (conflict-free), inputs as LDS broadcasts.
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
 #include "stq_dense.h"
 
 namespace l2hmc {
@@ -23,8 +27,23 @@ constexpr int kConvThreads = 256;
 // FT / LT: compile-time filter count and (square) lattice extent, 0 = take them from the arguments.  The index
 // arithmetic of every phase divides by F, X/2, ...: with constants these are shifts, with run-time values
 // ~30-instruction sequences that dominate the kernel.
+#ifdef L2HMC_STAMPS
+#define CF_STAMP(i)                                                                          \
+  do {                                                                                       \
+    if (p.stamps && threadIdx.x == 0) {                                                      \
+      unsigned long long t_;                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;               \
+    }                                                                                        \
+  } while (0)
+#else
+#define CF_STAMP(i) do {} while (0)
+#endif
+
 template <int FT, int LT>
-__global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArgs p) {
+__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void conv3d_front_kernel(ConvFrontArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int which = p.only ? p.only - 1 : blockIdx.y;   // 0: first input, 1: second input
   const int T = LT ? LT : p.T, X = LT ? LT : p.X, F = FT ? FT : p.F, F2 = 2 * F;
@@ -36,15 +55,254 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   // channel stride of the pooled conv1 map: F + 4 in the compile-time instances, whose second convolution runs on the
   // matrix pipe (16-byte fragment reads of 16 positions: rows of 20 / 12 floats fall on distinct bank groups)
   const int FS = FT ? F + 4 : F;
-  float* w1 = lds;                                 // [3][3][2][F]
-  float* b1 = w1 + 18 * F;
-  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice); FT > 0: [2F][4 F + 4] (g, tap * F + c)
-  float* b2 = w2 + (FT ? F2 * (4 * F + 4) : 4 * F * F2);
-  float* xin = b2 + F2;                            // [cpw][TP][XP][2]
-  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][FS]
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * cpw;
   const int nrow = (int)min((int64_t)cpw, p.rows - row0);
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  float* out = p.out[which];
+  if constexpr (FT > 0) {
+    // Compile-time shapes (the BASELINE configurations).  Round 4: NO weight goes through LDS -- a wave's conv1 taps
+    // are wave-uniform (scalar loads, SGPR operands) and a lane's conv2 fragments are read from the (L2-resident) Keras
+    // tensor straight into registers; only the halo cells are zeroed (disjoint from the staged interior: no barrier in
+    // between) and the chain is staged in 16-byte pieces.  LDS per workgroup is the two maps alone, so the launcher
+    // packs enough chains into a workgroup for ONE round of workgroups (launch_conv3d_front).
+    // Before (weights packed into LDS by every workgroup, whole-map zero fill, three barriers): 37.3 / 22.2 us per
+    // launch (both inputs / one) at 16 x 16, F = 16 with 40-46 % of the wave cycles parked
+    // (profiles/r03_pmc_cfg4_kernels.txt); now 25.5 / 14.6 us (profiles/r04_conv_fwd_stamps.txt).
+    constexpr int FP = FT / 2;
+    CF_STAMP(0);
+#ifdef L2HMC_STAMPS
+    if (p.stamps && threadIdx.x == 0) {              // where this workgroup runs: HW_ID | XCC_ID << 32, and the wall clock
+      unsigned hw, xcc;
+      unsigned long long rt;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+      p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 6] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+      p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 7] = rt;
+    }
+#endif
+    float* xin = lds;                                // [cpw][TP][XP][2]
+    float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][FS]
+    const float* gw1 = p.w1[which];
+    const float* gw2 = p.w2[which];
+    // ---- stage the chains (zero halo): element quad e .. e + 3 = sites s, s + 1 of one lattice row, both links
+    {
+      const float* in = p.in[which];
+      const bool masked = which == 1 && p.cmask_f != nullptr;
+      for (int i = tid; i < nrow * (D / 4); i += kConvThreads) {
+        const int c = i / (D / 4), e = (i - c * (D / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(in + (row0 + c) * p.ldi + e);
+        if (masked) {
+          const int d = p.dir ? p.dir[row0 + c] : 0;
+          v *= *reinterpret_cast<const f32x4*>((d ? p.cmask_b : p.cmask_f) + e);
+        }
+        const int site = e >> 1;
+        const int ii = site / X, jj = site - ii * X;
+        float* dst = xin + ((c * TP + ii + 1) * XP + jj + 1) * 2;       // 8-byte aligned (jj is even)
+        *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+      }
+      constexpr int NH = 2 * (LT + 2) + 2 * LT;        // halo cells of a chain: rows 0 and TP - 1, columns 0 and XP - 1
+      for (int i = tid; i < cpw * NH; i += kConvThreads) {
+        const int c = i / NH, h = i - c * NH;
+        const int hi = h < XP ? 0 : h < 2 * XP ? TP - 1 : h < 2 * XP + T ? 1 + (h - 2 * XP) : 1 + (h - 2 * XP - T);
+        const int hj = h < XP ? h : h < 2 * XP ? h - XP : h < 2 * XP + T ? 0 : XP - 1;
+        *reinterpret_cast<f32x2*>(xin + ((c * TP + hi) * XP + hj) * 2) = f32x2{0.f, 0.f};
+      }
+      constexpr int NP = (LT / 2 + 1) + LT / 2;        // pad cells of a pooled map: row T2 and column X2
+      constexpr int FS4 = (FT + 4) / 4;
+      for (int i = tid; i < cpw * NP * FS4; i += kConvThreads) {
+        const int c = i / (NP * FS4), rest = i - c * (NP * FS4);
+        const int h = rest / FS4, ch = (rest - h * FS4) * 4;
+        const int hi = h < X2P ? T2 : h - X2P, hj = h < X2P ? h : X2;
+        *reinterpret_cast<f32x4*>(p1 + ((c * T2P + hi) * X2P + hj) * FS + ch) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // conv2 operands of a lane: filter 16 gt + r, tap q, channels 4 s .. 4 s + 3 of the Keras tensor
+    // [di][dj][dd = 0][c][g], requested in front of the second barrier (earlier they cost the conv1 stage registers)
+    constexpr int PT = (LT / 2) * (LT / 2) / 16;        // 16-position tiles per chain (16 x 16: 4; 8 x 8: 1)
+    constexpr int GT = 2 * FT / 16;                     // 16-filter tiles (F = 16: 2; F = 8: 1)
+    constexpr int NS = FT / 4;                          // k-steps per tap group (4 channels each)
+    constexpr int RW = 16 / (LT / 2) < 1 ? 1 : 16 / (LT / 2);   // rows of the position grid per tile (2 or 4)
+    static_assert(LT / 2 <= 8 && (LT / 2) * (LT / 2) % 16 == 0 && (2 * FT) % 16 == 0 && FT % 4 == 0,
+                  "a 16-position tile must hold whole 2 x 2 pooling windows");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int di = q >> 1, dj = q & 1;
+    // ---- conv1 (VALU) and conv2 (matrix pipe), pipelined over groups of chains.  A group is as many chains as give
+    // every wave ONE conv2 tile (16 x 16: one chain, 8 x 8: four); the conv2 MFMAs of group g and the conv1 arithmetic
+    // of group g + 1 are independent and sit in one basic block, so the matrix pipe works under the packed VALU
+    // instructions instead of after them.  (Per CU and two-input launch at 16 x 16 the matrix pipe has 16 k cycles of
+    // work and the VALU 12-16 k; the counters of the shipped kernel read 27 % / 31 % of the SIMD cycles -- the four
+    // workgroups of a CU still finish between 10 and 23 us, i.e. one after the other rather than side by side.)
+    // conv1 (3,3,2) + relu + pool (2,2,2): a thread owns a PAIR of filters, so every multiply-add is a v_pk_fma_f32,
+    // and the 4 x 4 x 2 input patch under a pooling window is read once.
+    // conv2 (2,2,[2]) + relu + pool: per chain a [T2 X2 positions] x [4 F] x [2 F] product.  v_mfma_f32_16x16x4_f32
+    // with the WEIGHTS as first operand (16 filters x 4 k) and 16 positions as second: lane (q, r) supplies tap
+    // q = (di, dj) of position r, channels 4 s .. 4 s + 3 (one ds_read_b128 per step s, element e = channel 4 s + e), and
+    // receives out[position r][filters 16 gt + 4 q .. + 3].  A wave takes one 16-position tile with every filter tile;
+    // the 2 x 2 pooling partners of a position are lanes r ^ 1 and r ^ X2.
+    constexpr int CELLS = (LT / 2) * (LT / 2);
+    constexpr int CG = 4 / PT;                                   // chains per group
+    constexpr int IT1 = CG * CELLS * FP / kConvThreads;          // conv1 items per thread and group (16 x 16: 2; 8 x 8: 1)
+    static_assert(FT == 16 || FT == 8, "tap strides of the scalar loads");
+    static_assert(CG * PT == kConvThreads / 64 && CG * CELLS * FP == IT1 * kConvThreads && CG * CELLS == 64 &&
+                      FP == IT1 * (kConvThreads / 64),
+                  "one conv2 tile per wave and group; a wave's lanes are the cells of a group, its filter pairs uniform");
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: the taps go through the scalar cache
+    auto conv1_group = [&](int g, auto&& before_item) {
+#pragma unroll
+      for (int it = 0; it < IT1; ++it) {
+        before_item(it);
+        // this wave: filter pair fp of every cell of the group (lane = chain-in-group x cell); the pair's 18 taps are
+        // wave-uniform -- scalar loads, SGPR operands of the packed multiply-adds, no vector register
+        const int fp = wvu * IT1 + it;
+        // (scalar loads by hand: behind the kernel's own stores the compiler only issues vector loads, and hoisting
+        //  both items' taps out of the group loop wants 76 SGPRs)
+        unsigned long long kk[18], kb;
+        const float* tb = gw1 + 2 * fp;
+        const float* bb1 = p.b1[which] + 2 * fp;
+#define L2HMC_TAP_LOADS(ST)                                                                                          \
+  asm volatile("s_load_dwordx2 %0, %19, 0\n\ts_load_dwordx2 %1, %19, " #ST "*1\n\ts_load_dwordx2 %2, %19, " #ST "*2\n\t"     \
+               "s_load_dwordx2 %3, %19, " #ST "*3\n\ts_load_dwordx2 %4, %19, " #ST "*4\n\ts_load_dwordx2 %5, %19, " #ST "*5\n\t"  \
+               "s_load_dwordx2 %6, %19, " #ST "*6\n\ts_load_dwordx2 %7, %19, " #ST "*7\n\ts_load_dwordx2 %8, %19, " #ST "*8\n\t"  \
+               "s_load_dwordx2 %9, %19, " #ST "*9\n\ts_load_dwordx2 %10, %19, " #ST "*10\n\ts_load_dwordx2 %11, %19, " #ST "*11\n\t" \
+               "s_load_dwordx2 %12, %19, " #ST "*12\n\ts_load_dwordx2 %13, %19, " #ST "*13\n\ts_load_dwordx2 %14, %19, " #ST "*14\n\t" \
+               "s_load_dwordx2 %15, %19, " #ST "*15\n\ts_load_dwordx2 %16, %19, " #ST "*16\n\ts_load_dwordx2 %17, %19, " #ST "*17\n\t" \
+               "s_load_dwordx2 %18, %20, 0\n\ts_waitcnt lgkmcnt(0)"                                                   \
+               : "=&s"(kk[0]), "=&s"(kk[1]), "=&s"(kk[2]), "=&s"(kk[3]), "=&s"(kk[4]), "=&s"(kk[5]), "=&s"(kk[6]),       \
+                 "=&s"(kk[7]), "=&s"(kk[8]), "=&s"(kk[9]), "=&s"(kk[10]), "=&s"(kk[11]), "=&s"(kk[12]), "=&s"(kk[13]),   \
+                 "=&s"(kk[14]), "=&s"(kk[15]), "=&s"(kk[16]), "=&s"(kk[17]), "=&s"(kb)                                   \
+               : "s"(tb), "s"(bb1)                                                                                    \
+               : "memory")
+        if constexpr (FT == 16) L2HMC_TAP_LOADS(64);      // tap (t, d) of the pair: 4 F bytes apart
+        else L2HMC_TAP_LOADS(32);
+#undef L2HMC_TAP_LOADS
+        f32x2 k0[9], k1[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          k0[t] = __builtin_bit_cast(f32x2, kk[2 * t]);
+          k1[t] = __builtin_bit_cast(f32x2, kk[2 * t + 1]);
+        }
+        const f32x2 bias1 = __builtin_bit_cast(f32x2, kb);
+        const int cell = (tid & 63) % CELLS;
+        const int I = cell / X2, J = cell % X2, c = g * CG + (tid & 63) / CELLS;
+        f32x2 px[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+            px[a][bb] = *reinterpret_cast<const f32x2*>(xin + ((c * TP + 2 * I + a) * XP + 2 * J + bb) * 2);
+        f32x2 m = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            f32x2 v0 = bias1, v1 = bias1;    // output depth 0 sees (mu = 0, mu = 1), depth 1 sees (mu = 1, pad)
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) {
+#pragma unroll
+              for (int tj = 0; tj < 3; ++tj) {
+                const f32x2 xx = px[a + ti][bb + tj];
+                const f32x2 x0 = {xx[0], xx[0]}, x1 = {xx[1], xx[1]};
+                v0 += x0 * k0[ti * 3 + tj];       // (three fused multiply-adds per tap)
+                v0 += x1 * k1[ti * 3 + tj];
+                v1 += x1 * k0[ti * 3 + tj];
+              }
+            }
+            m[0] = fmaxf(m[0], fmaxf(v0[0], v1[0]));
+            m[1] = fmaxf(m[1], fmaxf(v0[1], v1[1]));
+          }
+        }
+        *reinterpret_cast<f32x2*>(p1 + ((c * T2P + I) * X2P + J) * FS + 2 * fp) = f32x2{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f)};
+        __builtin_amdgcn_sched_barrier(0);       // (one item's patch registers at a time)
+      }
+    };
+    f32x4 wf[GT][NS], bias2[GT], acc[GT];
+    const int c2l = wave / PT, pt = wave - c2l * PT;   // this wave's conv2 tile in a group: chain-in-group, tile
+    const int I = pt * RW + r / X2, J = r % X2;         // this lane's position
+    // the k-steps [S0, S1) of the wave's tile of group g
+    auto conv2_products = [&](int g, auto s0, auto s1) {
+      constexpr int S0 = decltype(s0)::value, S1 = decltype(s1)::value;
+      const float* pb = p1 + (((g * CG + c2l) * T2P + I + di) * X2P + J + dj) * FS;
+      if constexpr (S0 == 0) {
+#pragma unroll
+        for (int gt = 0; gt < GT; ++gt) acc[gt] = bias2[gt];
+      }
+#pragma unroll
+      for (int sx = S0; sx < S1; ++sx) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pb + 4 * sx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int gt = 0; gt < GT; ++gt)
+            acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gt][sx][e], a[e], acc[gt], 0, 0, 0);
+      }
+    };
+    auto conv2_finish = [&](int g) {      // relu + 2 x 2 max-pool across the position lanes (max and relu commute)
+      const int c = g * CG + c2l;
+#pragma unroll
+      for (int gt = 0; gt < GT; ++gt) {
+        f32x4 m = acc[gt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], X2 >= 16 ? 0 : X2, 64));
+          m[e] = fmaxf(m[e], 0.f);
+        }
+        if ((J & 1) == 0 && (I & 1) == 0 && c < nrow) {
+          float* o = out + (row0 + c) * p.ldo + ((I >> 1) * X4 + (J >> 1)) * F2 + 16 * gt + 4 * q;
+          *reinterpret_cast<f32x4*>(o) = m;
+        }
+      }
+    };
+    CF_STAMP(1);
+    __syncthreads();
+    CF_STAMP(2);
+    conv1_group(0, [](int) {});
+    CF_STAMP(3);
+    // conv2 operands of a lane: filter 16 gt + r, tap q, channels 4 s .. 4 s + 3 of the Keras tensor [di][dj][dd = 0][c][g]
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt)
+#pragma unroll
+      for (int sx = 0; sx < NS; ++sx)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wf[gt][sx][e] = gw2[((size_t)(q * 2) * F + 4 * sx + e) * F2 + 16 * gt + r];
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) bias2[gt] = *reinterpret_cast<const f32x4*>(p.b2[which] + 16 * gt + 4 * q);
+    __syncthreads();
+    CF_STAMP(4);
+    const int ng = (nrow + CG - 1) / CG;      // (a group's missing chains are computed on whatever their LDS holds; never stored)
+    using std::integral_constant;
+    static_assert(NS % IT1 == 0, "the tile's k-steps are dealt evenly over the conv1 items they run under");
+    for (int g = 0; g + 1 < ng; ++g) {
+      conv1_group(g + 1, [&](int it) {          // (it is a compile-time constant after unrolling)
+        if (it == 0) conv2_products(g, integral_constant<int, 0>{}, integral_constant<int, NS / IT1>{});
+        else conv2_products(g, integral_constant<int, NS / IT1>{}, integral_constant<int, NS>{});
+      });
+      conv2_finish(g);
+      __syncthreads();
+    }
+    conv2_products(ng - 1, integral_constant<int, 0>{}, integral_constant<int, NS>{});
+    conv2_finish(ng - 1);
+    CF_STAMP(5);
+#ifdef L2HMC_STAMPS
+    if (p.stamps && threadIdx.x == 0) {
+      unsigned long long rt;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+      p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = rt;
+    }
+#endif
+    return;
+  }
+  // ---- run-time shapes: filters and maps through LDS
+  float* w1 = lds;                                 // [3][3][2][F]
+  float* b1 = w1 + 18 * F;
+  float* w2 = b1 + F;                              // [2][2][F][2F]   (dd = 0 slice)
+  float* b2 = w2 + 4 * F * F2;
+  float* xin = b2 + F2;                            // [cpw][TP][XP][2]
+  float* p1 = xin + cpw * TP * XP * 2;             // [cpw][T2P][X2P][FS]
 
   const float* gw1 = p.w1[which];
   const float* gw2 = p.w2[which];
@@ -53,9 +311,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   for (int i = tid; i < 4 * F * F2; i += kConvThreads) {
     // Keras kernel [di][dj][dd][c][g]: keep dd = 0
     const int g = i % F2, c = (i / F2) % F, tap = i / (F2 * F);
-    const float wv = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
-    if (FT) w2[g * (4 * F + 4) + tap * F + c] = wv;      // k-contiguous per output filter: the MFMA's weight fragments
-    else w2[i] = wv;
+    w2[i] = gw2[((size_t)(tap * 2 + 0) * F + c) * F2 + g];
   }
   for (int i = tid; i < F2; i += kConvThreads) b2[i] = p.b2[which][i];
   for (int i = tid; i < cpw * TP * XP * 2; i += kConvThreads) xin[i] = 0.f;
@@ -76,121 +332,6 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
   }
   __syncthreads();
 
-  using f32x2 = __attribute__((ext_vector_type(2))) float;
-  float* out = p.out[which];
-  if constexpr (FT > 0) {
-    // Compile-time shapes (the BASELINE configurations): a thread owns a PAIR of filters, so every multiply-add is a
-    // v_pk_fma_f32; the pair's 18 conv1 taps stay in registers (the workgroup size is a multiple of F / 2) and the
-    // 4 x 4 x 2 input patch under a pooling window is read once (16 ds_read_b64 instead of 144 scalar reads).
-    constexpr int FP = FT / 2;
-    static_assert(kConvThreads % FP == 0 && FT % 2 == 0, "filter pairs must stay with their threads");
-    {
-      const int fp = tid % FP;
-      f32x2 k0[9], k1[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        k0[t] = *reinterpret_cast<const f32x2*>(w1 + (t * 2 + 0) * F + 2 * fp);
-        k1[t] = *reinterpret_cast<const f32x2*>(w1 + (t * 2 + 1) * F + 2 * fp);
-      }
-      const f32x2 bias = *reinterpret_cast<const f32x2*>(b1 + 2 * fp);
-      const int n1 = nrow * T2 * X2 * FP;
-      for (int idx = tid; idx < n1; idx += kConvThreads) {
-        int r = idx / FP;
-        const int J = r % X2;
-        r /= X2;
-        const int I = r % T2, c = r / T2;
-        f32x2 px[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb)
-            px[a][bb] = *reinterpret_cast<const f32x2*>(xin + ((c * TP + 2 * I + a) * XP + 2 * J + bb) * 2);
-        f32x2 m = {-INFINITY, -INFINITY};
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb) {
-            f32x2 v0 = bias, v1 = bias;      // output depth 0 sees (mu = 0, mu = 1), depth 1 sees (mu = 1, pad)
-#pragma unroll
-            for (int di = 0; di < 3; ++di) {
-#pragma unroll
-              for (int dj = 0; dj < 3; ++dj) {
-                const f32x2 xx = px[a + di][bb + dj];
-                const f32x2 x0 = {xx[0], xx[0]}, x1 = {xx[1], xx[1]};
-                v0 += x0 * k0[di * 3 + dj] + x1 * k1[di * 3 + dj];
-                v1 += x1 * k0[di * 3 + dj];
-              }
-            }
-            m[0] = fmaxf(m[0], fmaxf(v0[0], v1[0]));
-            m[1] = fmaxf(m[1], fmaxf(v0[1], v1[1]));
-          }
-        }
-        *reinterpret_cast<f32x2*>(p1 + ((c * T2P + I) * X2P + J) * FS + 2 * fp) = f32x2{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f)};
-      }
-    }
-    __syncthreads();
-    // conv2 (2,2,[2]) + relu + pool on the matrix pipe: per chain a [T2 X2 positions] x [4 F] x [2 F] product.
-    // v_mfma_f32_16x16x4_f32 with the WEIGHTS as first operand (16 filters x 4 k) and 16 positions as second: lane
-    // (q, r) supplies tap q = (di, dj) of position r, channels 4 s .. 4 s + 3 (one ds_read_b128 per step s, element e =
-    // channel 4 s + e), and receives out[position r][filters 16 gt + 4 q .. + 3].  A wave takes one 16-position tile
-    // with every filter tile; the 2 x 2 pooling partners of a position are lanes r ^ 1 and r ^ X2.
-    // (The VALU form this replaces spent 25 LDS reads per 64 packed multiply-adds: LDS-throughput-bound.)
-    {
-      constexpr int PT = (LT / 2) * (LT / 2) / 16;        // 16-position tiles per chain (16 x 16: 4; 8 x 8: 1)
-      constexpr int GT = 2 * FT / 16;                     // 16-filter tiles (F = 16: 2; F = 8: 1)
-      constexpr int NS = FT / 4;                          // k-steps per tap group (4 channels each)
-      constexpr int RW = 16 / (LT / 2) < 1 ? 1 : 16 / (LT / 2);   // rows of the position grid per tile (2 or 4)
-      constexpr int WK = 4 * FT + 4;
-      static_assert(LT / 2 <= 8 && (LT / 2) * (LT / 2) % 16 == 0 && (2 * FT) % 16 == 0 && FT % 4 == 0,
-                    "a 16-position tile must hold whole 2 x 2 pooling windows");
-      const int lane = tid & 63, wave = tid >> 6;
-      const int q = lane >> 4, r = lane & 15;
-      const int di = q >> 1, dj = q & 1;
-      // this lane's weight fragments: filter 16 gt + r, tap q, channels 4 s .. 4 s + 3
-      f32x4 wf[GT][NS];
-#pragma unroll
-      for (int gt = 0; gt < GT; ++gt)
-#pragma unroll
-        for (int sx = 0; sx < NS; ++sx)
-          wf[gt][sx] = *reinterpret_cast<const f32x4*>(w2 + (16 * gt + r) * WK + q * FT + 4 * sx);
-      f32x4 bias[GT];
-#pragma unroll
-      for (int gt = 0; gt < GT; ++gt) bias[gt] = *reinterpret_cast<const f32x4*>(b2 + 16 * gt + 4 * q);
-      for (int item = wave; item < nrow * PT; item += kConvThreads / 64) {
-        const int c = item / PT, pt = item - c * PT;
-        const int I = pt * RW + r / X2, J = r % X2;       // this lane's position
-        const float* pb = p1 + ((c * T2P + I + di) * X2P + J + dj) * FS;
-        f32x4 acc[GT];
-#pragma unroll
-        for (int gt = 0; gt < GT; ++gt) acc[gt] = bias[gt];
-#pragma unroll
-        for (int sx = 0; sx < NS; ++sx) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(pb + 4 * sx);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int gt = 0; gt < GT; ++gt)
-              acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gt][sx][e], a[e], acc[gt], 0, 0, 0);
-        }
-        // relu + 2 x 2 max-pool across the position lanes (max and relu commute)
-#pragma unroll
-        for (int gt = 0; gt < GT; ++gt) {
-          f32x4 m = acc[gt];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            m[e] = fmaxf(m[e], __shfl_xor(m[e], 1, 64));
-            m[e] = fmaxf(m[e], __shfl_xor(m[e], X2 >= 16 ? 0 : X2, 64));
-            m[e] = fmaxf(m[e], 0.f);
-          }
-          if ((J & 1) == 0 && (I & 1) == 0) {
-            float* o = out + (row0 + c) * p.ldo + ((I >> 1) * X4 + (J >> 1)) * F2 + 16 * gt + 4 * q;
-            *reinterpret_cast<f32x4*>(o) = m;
-          }
-        }
-      }
-    }
-    return;
-  }
   // ---- conv1 (3,3,2) + relu + pool (2,2,2): pooled output (c, I, J, f), f on the lane
   const int n1 = nrow * T2 * X2 * F;
   for (int idx = tid; idx < n1; idx += kConvThreads) {
@@ -265,19 +406,46 @@ __global__ __launch_bounds__(kConvThreads) void conv3d_front_kernel(ConvFrontArg
 
 int conv3d_nflat(int T, int X, int F) { return (T / 4) * (X / 4) * 2 * F; }
 
+// CUs of the current device; asked once per device
+static int conv_cu_count() {
+  static std::atomic<int> cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
   L2HMC_REQUIRE(a.T % 4 == 0 && a.X % 4 == 0 && a.F > 0 && a.F % 4 == 0,
                 "conv3d front-end: T=%d X=%d F=%d must be multiples of 4", a.T, a.X, a.F);
+  if (a.ldi == 0) a.ldi = 2 * a.T * a.X;
+  // compile-time instances (pooled map with channel stride F + 4, no weights in LDS, 16-byte staging loads): the
+  // BASELINE shapes with 16-byte-aligned operands; everything else takes the run-time form
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  bool inst = ((a.F == 8 && a.T == 8 && a.X == 8) || (a.F == 16 && a.T == 16 && a.X == 16)) && a.ldi % 4 == 0 &&
+              a.ldo % 4 == 0 && (!a.cmask_f || (al16(a.cmask_f) && al16(a.cmask_b)));
+  for (int w = 0; w < 2 && inst; ++w)
+    if (a.only == 0 || a.only == w + 1)
+      inst = al16(a.in[w]) && al16(a.out[w]) && al16(a.w1[w]) && al16(a.b1[w]) && al16(a.w2[w]) && al16(a.b2[w]);
   const int per_chain = (a.T / 2) * (a.X / 2) * a.F;
   a.cpw = per_chain >= 1024 ? 1 : (1024 / per_chain > 8 ? 8 : 1024 / per_chain);   // amortise filter loads / barriers
   if (per_chain >= 1024 && per_chain < 4096) a.cpw = 2;      // 16 x 16, F = 16: 32.7 -> 31.0 us per launch (two chains share the filter load)
-  if (a.ldi == 0) a.ldi = 2 * a.T * a.X;
-  // compile-time instances: k-contiguous conv2 weights with a 4-float row pad, pooled map with channel stride F + 4
-  const bool inst = (a.F == 8 && a.T == 8 && a.X == 8) || (a.F == 16 && a.T == 16 && a.X == 16);
-  const size_t fs = inst ? a.F + 4 : a.F;
-  const size_t lds = sizeof(float) * ((size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + (inst ? 8 * a.F : 0) + 2 * a.F +
-                                      (size_t)a.cpw * (a.T + 2) * (a.X + 2) * 2 +
-                                      (size_t)a.cpw * (a.T / 2 + 1) * (a.X / 2 + 1) * fs);
+  const size_t maps = (size_t)(a.T + 2) * (a.X + 2) * 2 + (size_t)(a.T / 2 + 1) * (a.X / 2 + 1) * (inst ? a.F + 4 : a.F);
+  if (inst) {
+    // the maps are all of a workgroup's LDS: as many chains per workgroup as keep (about) four workgroups per CU
+    // in ONE round -- the batch over 4 x CUs workgroups per input, at most what 40 KB hold, at least the default
+    const int64_t want = ceil_div(a.rows * (a.only ? 1 : 2), (int64_t)4 * conv_cu_count());
+    const int64_t fit = (int64_t)(40 * 1024 / sizeof(float) / maps);
+    a.cpw = (int)std::max<int64_t>(a.cpw, std::min<int64_t>(want, fit));
+    const int cg = a.T == 8 ? 4 : 1;            // (kernel: CG, chains per pipeline group)
+    a.cpw = (a.cpw + cg - 1) / cg * cg;
+  }
+  const size_t lds = sizeof(float) * (inst ? (size_t)a.cpw * maps
+                                           : (size_t)18 * a.F + a.F + (size_t)8 * a.F * a.F + 2 * a.F + (size_t)a.cpw * maps);
   L2HMC_REQUIRE(lds <= 160 * 1024, "conv3d front-end: %zu B of LDS needed", lds);
   L2HMC_REQUIRE(a.only >= 0 && a.only <= 2, "conv3d front-end: bad input selector %d", a.only);
   const dim3 grid((unsigned)ceil_div(a.rows, a.cpw), a.only ? 1 : 2);
@@ -291,10 +459,13 @@ int launch_conv3d_front(ConvFrontArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.done();
   }
+#ifdef L2HMC_STAMPS
+  a.stamps = g_stamp_cls == 7 ? g_stamp_buf : nullptr;
+#endif
   prof_before(kProfConvFront, stream);
-  if (a.F == 8 && a.T == 8 && a.X == 8)
+  if (inst && a.F == 8)
     hipLaunchKernelGGL((conv3d_front_kernel<8, 8>), grid, dim3(kConvThreads), lds, stream, a);
-  else if (a.F == 16 && a.T == 16 && a.X == 16)
+  else if (inst)
     hipLaunchKernelGGL((conv3d_front_kernel<16, 16>), grid, dim3(kConvThreads), lds, stream, a);
   else
     hipLaunchKernelGGL((conv3d_front_kernel<0, 0>), grid, dim3(kConvThreads), lds, stream, a);

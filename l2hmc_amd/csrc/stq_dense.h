@@ -104,6 +104,7 @@ struct ConvFrontArgs {
   int cpw;                               // chains per workgroup (set by the launcher)
   int ldi;                               // row stride of `in` (0 = 2*T*X)
   int only;                              // 0: both inputs; 1: the first input only; 2: the second input only
+  unsigned long long* stamps;            // diagnostic builds only (class 7): phase boundaries per workgroup
 };
 
 // backward of the front-end (training path); input `which` lives at column offset which*D of `in` / `din`
