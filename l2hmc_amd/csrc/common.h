@@ -101,6 +101,28 @@ __device__ __forceinline__ f32x4_t buf_load16(const WSection& ws, unsigned lane_
   return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, lane_off_bytes, uniform_off_bytes, 0));
 }
 
+// The same source as a plain descriptor (four scalar registers) for the loads that go STRAIGHT to LDS: issued by
+// hand, because the compiler orders every LDS read behind a load-to-LDS it knows of (it cannot tell the buffer being
+// filled from the one being read) -- the caller waits with s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+struct WDesc {
+  u32x4_t d;
+};
+__device__ __forceinline__ WDesc wdesc(const float* __restrict__ base) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  return {u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)), 0x7fffffffu, 0x00020000u}};
+}
+// 16 bytes per lane from base + lane_off_bytes + uniform_off_bytes to LDS byte address lds_addr (wave-uniform) + 16 * lane
+__device__ __forceinline__ void lds_dma16(const WDesc& w, unsigned lds_addr, unsigned lane_off_bytes, unsigned uniform_off_bytes) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(lane_off_bytes), "s"(w.d), "s"(uniform_off_bytes)
+               : "memory");      // (m0 is reserved: the compiler keeps nothing in it)
+}
+__device__ __forceinline__ unsigned lds_byte_address(const float* p) {
+  return (unsigned)reinterpret_cast<unsigned long>((const __attribute__((address_space(3))) float*)p);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_take(float v) {          // lanes of rows outside ROW_MASK receive 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));

@@ -55,14 +55,27 @@ __device__ __forceinline__ float l1_preact(float acc, float bj, float tc, float 
 template <int BM, int KIND, int BK, int BN = 128, bool RAGGED = false>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void gemm_relu_kernel(GemmReluArgs p) {
   constexpr int CPR = BK / 4;              // 16-byte chunks per staged row
-  constexpr int LDK = BK + 4;              // rows of 36 / 68 floats: an odd number of 16-B slots => conflict-free b128 reads
+  // Aligned shapes (DMA): the tiles go from global memory STRAIGHT into LDS (buffer_load ... lds, 1 KiB per wave
+  // instruction, no staging registers, no ds_write; round 4 -- the no-staging experiment of
+  // profiles/r04_cfg4_experiments.txt put what staging costs at 7-12 % of the kernel).  Such a load fills 1 KiB of LDS
+  // in lane order, so rows cannot be padded; instead chunk c of row R sits at position c ^ swz(R), the lane asking for
+  // the global chunk that belongs at ITS position.  swz is even (a fragment's two half-wave chunks 2 kq, 2 kq + 1 stay
+  // neighbours) and spreads the 32 rows x 2 halves of a fragment read evenly over the 16 bank groups.
+  // Otherwise: staged through registers into padded rows (36 / 68 floats: an odd number of 16-B slots).
+  // k-tiles of 32 (the 128-row instances of cfg 5) keep the register path: measured 754 against 748 ms per cfg-5 step.
+  constexpr bool DMA = !RAGGED && BK == 64;
+  constexpr int LDK = DMA ? BK : BK + 4;
+  constexpr int RP = 64 / BK;              // rows per 256 bytes of LDS
+  auto swz = [](int R) { return DMA ? 2 * ((R / RP) & (CPR / 2 - 1)) : 0; };
   constexpr int MT = BM / 64;              // 32x32 tiles per wave along M (wave grid 2 x 2)
   constexpr int WN = BN / 2;               // columns per wave: 64 (BN = 128) or 32 (BN = 64)
   constexpr int NT = WN / 32;
   constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
   constexpr int B_CH = BN * (BK / 4) / kGemmThreads;
   constexpr int STAGE = (BM + BN) * LDK;   // one A|B buffer pair
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int LDC = BN + 4;              // row stride of the output tile staged by the epilogue (floats)
+  constexpr int LDS_FLOATS = (RAGGED || 2 * STAGE >= BM * LDC) ? 2 * STAGE : BM * LDC;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   L2HMC_STAMP_REAL(4);
   L2HMC_STAMP(0);
@@ -70,6 +83,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);     // provably uniform (LDS addresses of the tile loads)
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt_id = tile / p.ntiles, nt_id = tile - mt_id * p.ntiles;
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
     a_row[i] = c / CPR;
-    a_kc[i] = (c % CPR) * 4;
+    a_kc[i] = ((c % CPR) ^ swz(a_row[i])) * 4;          // the k-chunk that belongs at LDS position c
     a_ok[i] = (m0 + a_row[i]) < p.rows;
     a_dir[i] = (KIND == 1 && p.dir && a_ok[i]) ? p.dir[m0 + a_row[i]] : 0;
   }
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + i * kGemmThreads;
     b_row[i] = c / CPR;
-    b_kc[i] = (c % CPR) * 4;
+    b_kc[i] = ((c % CPR) ^ swz(b_row[i])) * 4;
     b_ok[i] = (n0 + b_row[i]) < p.N;
   }
 
@@ -112,10 +126,15 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   [[maybe_unused]] bool tile_masked = false;
   [[maybe_unused]] unsigned a_off1[A_CH], a_off2[A_CH], b_off[B_CH];      // bytes from the tile's base (launcher: < 2^31)
   [[maybe_unused]] WSection rs_a1, rs_a2, rs_b;
+  [[maybe_unused]] WDesc ds_a1, ds_a2, ds_b;
+  [[maybe_unused]] const unsigned lds0 = lds_byte_address(lds);
   if constexpr (!RAGGED) {
     rs_a1 = wsection(p.A1 + m0 * p.lda1);
     rs_a2 = wsection((KIND != 2 && p.A2) ? p.A2 + m0 * p.lda2 : p.A1 + m0 * p.lda1);
     rs_b = wsection(p.Wt + (int64_t)n0 * p.K);
+    ds_a1 = wdesc(p.A1 + m0 * p.lda1);
+    ds_a2 = wdesc((KIND != 2 && p.A2) ? p.A2 + m0 * p.lda2 : p.A1 + m0 * p.lda1);
+    ds_b = wdesc(p.Wt + (int64_t)n0 * p.K);
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const unsigned lr = (unsigned)((a_ok[i] ? m0 + a_row[i] : p.rows - 1) - m0);     // clamped row, tile-local
@@ -128,7 +147,9 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
       b_off[i] = (lc * (unsigned)p.K + (unsigned)b_kc[i]) * 4u;
     }
   }
-  auto load_tile = [&](int kt) {
+  // buf: the LDS buffer the tile is for (DMA: the loads go there at once; the barrier at the end of the previous
+  // k-tile is what freed it)
+  auto load_tile = [&](int kt, [[maybe_unused]] int buf) {
     const int k0 = kt * BK;
     if constexpr (RAGGED) {
 #pragma unroll
@@ -164,40 +185,73 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     } else {
       const bool second = KIND != 2 && k0 >= p.K1;            // uniform
       const int kk0 = second ? k0 - p.K1 : k0;
-      if (second) {
+      [[maybe_unused]] const unsigned la = lds0 + (unsigned)(buf * STAGE) * 4u + (unsigned)wv * 1024u;
+      [[maybe_unused]] const unsigned lb = la + (unsigned)(BM * LDK) * 4u;
+      if constexpr (KIND == 1) tile_masked = second && p.cmask_f != nullptr;
+      if constexpr (!DMA) {
+        if (second) {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a2, a_off2[i], (unsigned)kk0 * 4u);
+        } else {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a1, a_off1[i], (unsigned)kk0 * 4u);
+        }
+        if constexpr (KIND == 1) {
+          if (tile_masked) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i)
+              rm[i] = *reinterpret_cast<const f32x4*>((a_dir[i] ? p.cmask_b : p.cmask_f) + kk0 + a_kc[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_off[i], (unsigned)k0 * 4u);
+        return;
+      }
+      if (KIND == 1 && tile_masked) {
+        // the second input's column mask is multiplied in on the way: this tile's A goes through registers
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a2, a_off2[i], (unsigned)kk0 * 4u);
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+          rm[i] = *reinterpret_cast<const f32x4*>((a_dir[i] ? p.cmask_b : p.cmask_f) + kk0 + a_kc[i]);
+      } else if (second) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) lds_dma16(ds_a2, la + (unsigned)i * 4096u, a_off2[i], (unsigned)kk0 * 4u);
       } else {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a1, a_off1[i], (unsigned)kk0 * 4u);
-      }
-      if constexpr (KIND == 1) {
-        tile_masked = second && p.cmask_f != nullptr;
-        if (tile_masked) {
-#pragma unroll
-          for (int i = 0; i < A_CH; ++i)
-            rm[i] = *reinterpret_cast<const f32x4*>((a_dir[i] ? p.cmask_b : p.cmask_f) + kk0 + a_kc[i]);
-        }
+        for (int i = 0; i < A_CH; ++i) lds_dma16(ds_a1, la + (unsigned)i * 4096u, a_off1[i], (unsigned)kk0 * 4u);
       }
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_off[i], (unsigned)k0 * 4u);
+      for (int i = 0; i < B_CH; ++i) lds_dma16(ds_b, lb + (unsigned)i * 4096u, b_off[i], (unsigned)k0 * 4u);
     }
   };
+  // the tile is complete in LDS when this returns (the caller's barrier publishes it)
   auto store_tile = [&](int buf) {
     float* ab = lds + buf * STAGE;
     float* bb = ab + BM * LDK;
-    if constexpr (KIND == 1 && !RAGGED) {
-      if (tile_masked) {
+    if constexpr (DMA) {
+      if constexpr (KIND == 1) {
+        if (tile_masked) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] *= rm[i];
+          for (int i = 0; i < A_CH; ++i)                       // position (tid + 256 i): the chunk a_kc was chosen for
+            *reinterpret_cast<f32x4*>(ab + (tid + i * kGemmThreads) * 4) = ra[i] * rm[i];
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's loads-to-LDS have landed
+    } else {
+      if constexpr (KIND == 1 && !RAGGED) {
+        if (tile_masked) {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i) ra[i] *= rm[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i)
+        *reinterpret_cast<f32x4*>(ab + a_row[i] * LDK + a_kc[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        *reinterpret_cast<f32x4*>(bb + b_row[i] * LDK + b_kc[i]) = rb[i];
     }
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i)
-      *reinterpret_cast<f32x4*>(ab + a_row[i] * LDK + a_kc[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i)
-      *reinterpret_cast<f32x4*>(bb + b_row[i] * LDK + b_kc[i]) = rb[i];
   };
 
   f32x16 acc[MT][NT];
@@ -244,13 +298,16 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   }
 
   const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
-  load_tile(kt0);
+  load_tile(kt0, 0);
   store_tile(0);
   __syncthreads();
   L2HMC_STAMP(1);
+  // position of a fragment's chunk pair (2 kq, 2 kq + 1) in this lane's rows: (8 kq) ^ xa / xb floats into the row
+  // (rows 32 apart share their swizzle)
+  const int xa = swz(wm * (BM / 2) + r) * 4, xb = swz(wn * WN + r) * 4;
   for (int kt = kt0; kt < nk; ++kt) {
     const int cur = (kt - kt0) & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);   // in flight under the MFMAs below
+    if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);   // in flight under the MFMAs below
     const float* as = lds + cur * STAGE + (wm * (BM / 2) + r) * LDK + half * 4;
     const float* bs = lds + cur * STAGE + BM * LDK + (wn * WN + r) * LDK + half * 4;
     // the fragments of k-step group kq + 1 are read from LDS while group kq's MFMAs issue (two register sets): read
@@ -258,17 +315,19 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     // latency of the reads in front of it (ISA: four ds_read_b128, s_waitcnt lgkmcnt, eight MFMAs, ...)
     f32x4 af[2][MT], bf[2][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK);
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + (0 ^ xa));
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK);
+    for (int j = 0; j < NT; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + (0 ^ xb));
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       const int cb = kq & 1, nb = cb ^ 1;
       if (kq + 1 < BK / 8) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + (kq + 1) * 8);
+        for (int i = 0; i < MT; ++i)
+          af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + (((kq + 1) * 8) ^ xa));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + (kq + 1) * 8);
+        for (int j = 0; j < NT; ++j)
+          bf[nb][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + (((kq + 1) * 8) ^ xb));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -294,8 +353,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
   // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   // Aligned shapes: the tile goes through LDS (the stage buffers are free) and leaves as 16-byte pieces of whole rows
   // -- a wave's store instruction covers 2 x 512 contiguous bytes instead of 2 x 128.
-  constexpr int LDC = BN + 4;                           // row stride of the staged tile (floats)
-  static_assert(RAGGED || BM * LDC <= 2 * STAGE, "the output tile must fit the stage buffers");
+  static_assert(RAGGED || BM * LDC <= LDS_FLOATS, "the output tile must fit the stage buffers");
   const bool staged = !RAGGED && (p.ldo % 4) == 0 && (p.N % 4) == 0 && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -439,7 +497,13 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   constexpr int BNH = 32, NB = 3 * BNH;
   constexpr int RG = BM / 32;             // 16-row groups per wave (wave grid 2 x 2: BM / 2 rows x 16 columns per wave)
   constexpr int CPR = BK / 4;
-  constexpr int LDK = BK + 8;             // 40 / 72 floats (= 8 mod 64): conflict-free for the 16-row fragment reads
+  // Aligned shapes with k-tiles of 32 (DMA): the tiles go from global memory straight into LDS (gemm_relu_kernel has
+  // the story).  Rows are 128 unpadded bytes; row R keeps its two 64-byte halves (k-steps kh = 0, 1) swapped when
+  // (R >> 1) & 1: the 16 rows x 4 quarter-chunks of a fragment read then fall on 16 distinct 16-byte bank groups.
+  // Otherwise rows of 40 / 72 floats (= 8 mod 64): conflict-free for the 16-row fragment reads.
+  constexpr bool DMA = !RAGGED && BK == 32;
+  constexpr int LDK = DMA ? BK : BK + 8;
+  auto swz = [](int R) { return DMA ? 4 * ((R >> 1) & 1) : 0; };     // in 16-byte chunks
   constexpr int A_CH = BM * (BK / 4) / kGemmThreads;
   constexpr int B_CH = NB * (BK / 4) / kGemmThreads;
   constexpr int STAGE = (BM + NB) * LDK;
@@ -451,6 +515,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, r = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
 
   // Active-column form (HeadsArgs::cols_f): the tiles are walked column block by column block in launch order, so the
   // column blocks past the end of the list -- which leave at once -- come last and the live workgroups spread over
@@ -471,7 +536,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
     a_row[i] = c / CPR;
-    a_kc[i] = (c % CPR) * 4;
+    a_kc[i] = ((c % CPR) ^ swz(a_row[i])) * 4;           // the k-chunk that belongs at LDS position c
     a_ok[i] = (m0 + a_row[i]) < p.rows;
   }
   int b_row[B_CH], b_kc[B_CH];
@@ -481,7 +546,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + i * kGemmThreads;
     b_row[i] = c / CPR;                     // 0..95 = head * 32 + nn
-    b_kc[i] = (c % CPR) * 4;
+    b_kc[i] = ((c % CPR) ^ swz(b_row[i])) * 4;
     const int hd = b_row[i] >> 5, nn = b_row[i] & 31;
     b_ok[i] = (n0 + nn) < ncol;
     const int wcol = cols ? cols[b_ok[i] ? n0 + nn : ncol - 1] : n0 + nn;
@@ -491,10 +556,14 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   // weights at their start (launcher: 3 D K floats < 2 GiB); a chunk outside the tile / the column list points its
   // lane beyond the resource's window and reads 0, so every load is unconditional
   [[maybe_unused]] WSection rs_a, rs_b;
+  [[maybe_unused]] WDesc ds_a, ds_b;
   [[maybe_unused]] unsigned a_boff[A_CH], b_boff[B_CH];
+  [[maybe_unused]] const unsigned lds0 = lds_byte_address(lds);
   if constexpr (!RAGGED) {
     rs_a = wsection(p.A + m0 * p.lda);
     rs_b = wsection(p.Wt);
+    ds_a = wdesc(p.A + m0 * p.lda);
+    ds_b = wdesc(p.Wt);
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       a_boff[i] = a_ok[i] ? ((unsigned)a_row[i] * (unsigned)p.lda + (unsigned)a_kc[i]) * 4u : 0xfffffff0u;
@@ -503,8 +572,16 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
   }
 
   f32x4 ra[A_CH], rb[B_CH];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, [[maybe_unused]] int buf) {
     const int k0 = kt * BK;
+    if constexpr (DMA) {
+      const unsigned la = lds0 + (unsigned)(buf * STAGE) * 4u + (unsigned)wv * 1024u, lb = la + (unsigned)(BM * LDK) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) lds_dma16(ds_a, la + (unsigned)i * 4096u, a_boff[i], (unsigned)k0 * 4u);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) lds_dma16(ds_b, lb + (unsigned)i * 4096u, b_boff[i], (unsigned)k0 * 4u);
+      return;
+    }
     if constexpr (!RAGGED) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a, a_boff[i], (unsigned)k0 * 4u);
@@ -542,6 +619,10 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's loads-to-LDS have landed
+      return;
+    }
     float* ab = lds + buf * STAGE;
     float* bb = ab + BM * LDK;
 #pragma unroll
@@ -559,13 +640,15 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     for (int j = 0; j < RG; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = RAGGED ? (p.K + BK - 1) / BK : p.K / BK;
-  load_tile(0);
+  load_tile(0, 0);
   store_tile(0);
   __syncthreads();
   L2HMC_STAMP(1);
+  // (rows 16 apart and the three heads' rows, 32 apart, share their swizzle)
+  const int xa = swz(wm * (BM / 2) + r) * 4, xb = swz(wn * 16 + r) * 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
     // wave (wm, wn): rows [32 wm, 32 wm + 32) x columns [16 wn, 16 wn + 16) of all three heads -- per 16 k two row
     // fragments and three column fragments feed 24 MFMAs (5 ds_read_b128; a wave owning 16 rows x all 96 columns
     // read 7)
@@ -574,17 +657,19 @@ __global__ __launch_bounds__(kGemmThreads) void heads_kernel(HeadsArgs p) {
     // (fragments of group kh + 1 are read while group kh's MFMAs issue: gemm_relu_kernel)
     f32x4 af[2][RG], bf[2][3];
 #pragma unroll
-    for (int i = 0; i < RG; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK);
+    for (int i = 0; i < RG; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + (0 ^ xa));
 #pragma unroll
-    for (int h = 0; h < 3; ++h) bf[0][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK);
+    for (int h = 0; h < 3; ++h) bf[0][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + (0 ^ xb));
 #pragma unroll
     for (int kh = 0; kh < BK / 16; ++kh) {
       const int cb = kh & 1, nb = cb ^ 1;
       if (kh + 1 < BK / 16) {
 #pragma unroll
-        for (int i = 0; i < RG; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + (kh + 1) * 16);
+        for (int i = 0; i < RG; ++i)
+          af[nb][i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK + (((kh + 1) * 16) ^ xa));
 #pragma unroll
-        for (int h = 0; h < 3; ++h) bf[nb][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + (kh + 1) * 16);
+        for (int h = 0; h < 3; ++h)
+          bf[nb][h] = *reinterpret_cast<const f32x4*>(bs + h * 32 * LDK + (((kh + 1) * 16) ^ xb));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
