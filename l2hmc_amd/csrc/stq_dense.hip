@@ -758,6 +758,7 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, r = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
 
   // Active-column form (HeadsArgs::cols_f): the tiles are walked column block by column block in launch order, so the
   // column blocks past the end of the list -- which leave at once -- come last and the live workgroups spread over
@@ -772,45 +773,37 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
   const int ncol = cols ? *(m0 >= p.dir_split ? p.cnt_b : p.cnt_f) : p.D;
   if (n0 >= ncol) return;                  // (uniform; before any barrier)
 
-  // unconditional, clamped tile loads (rows past the end repeat the last row: their products are never stored)
-  // (buffer loads, common.h: buf_load16 -- A based at this tile's first row, the weights at their start)
-  const WSection rs_a = wsection(p.A + m0 * p.lda), rs_b = wsection(p.Wt);
+  // unconditional, clamped tile loads (rows past the end repeat the last row: their products are never stored),
+  // straight into LDS (common.h: lds_dma16; gemm_relu_kernel has the story): the lane at LDS position c of a tile
+  // asks for the chunk that belongs there -- A based at this tile's first row, the weights at their start
+  const WDesc ds_a = wdesc(p.A + m0 * p.lda), ds_b = wdesc(p.Wt);
+  const unsigned lds0 = lds_byte_address(lds);
   unsigned a_src[A_CH];
-  int a_off[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    const int row = c / CPR, kc = (c % CPR) * 4;
+    const int row = c / CPR, kc = ((c % CPR) ^ ((row >> 2) & 3)) * 4;
     const int64_t g = (m0 + row) < p.rows ? m0 + row : p.rows - 1;
     a_src[i] = ((unsigned)(g - m0) * (unsigned)p.lda + (unsigned)kc) * 4u;
-    a_off[i] = row * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
   unsigned b_src[B_CH];
-  int b_off[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + i * kGemmThreads;
-    const int row = c / CPR, kc = (c % CPR) * 4;     // row = head * 64 + nn
+    const int row = c / CPR, kc = ((c % CPR) ^ ((row >> 2) & 3)) * 4;     // row = head * 64 + nn
     const int hd = row >> 6, nn = row & 63;
     const int cidx = (n0 + nn) < ncol ? n0 + nn : ncol - 1;
     const int col = cols ? cols[cidx] : cidx;
     b_src[i] = (unsigned)((((int64_t)hd * p.D + col) * p.K + kc) * 4);
-    b_off[i] = (BM + row) * LDK + (((kc >> 2) ^ ((row >> 2) & 3)) << 2);
   }
-  f32x4 ra[A_CH], rb[B_CH];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, int buf) {
+    const unsigned la = lds0 + (unsigned)(buf * STAGE) * 4u + (unsigned)wv * 1024u, lb = la + (unsigned)(BM * LDK) * 4u;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rs_a, a_src[i], (unsigned)(kt * BK) * 4u);
+    for (int i = 0; i < A_CH; ++i) lds_dma16(ds_a, la + (unsigned)i * 4096u, a_src[i], (unsigned)(kt * BK) * 4u);
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rs_b, b_src[i], (unsigned)(kt * BK) * 4u);
+    for (int i = 0; i < B_CH; ++i) lds_dma16(ds_b, lb + (unsigned)i * 4096u, b_src[i], (unsigned)(kt * BK) * 4u);
   };
-  auto store_tile = [&](int buf) {
-    float* st = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<f32x4*>(st + a_off[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<f32x4*>(st + b_off[i]) = rb[i];
-  };
+  auto store_tile = [&](int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };   // this wave's loads have landed
 
   f32x16 acc[2][3];
 #pragma unroll
@@ -821,12 +814,12 @@ __global__ __launch_bounds__(kGemmThreads) void heads32_kernel(HeadsArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][h][e] = 0.f;
 
   const int nk = p.K / BK;
-  load_tile(0);
+  load_tile(0, 0);
   store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
     // (every row offset below is a multiple of 32, so the swizzle term (row >> 2) & 3 is that of r alone)
     const int sw = (r >> 2) & 3;
     const float* as = lds + cur * STAGE + (wm * 64 + r) * LDK;
