@@ -355,7 +355,8 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
             const float* px = xin + ((c * TP + i + di) * XP + j + dj) * 2;   // halo shifts by +1, tap by -1
             const float x0 = px[0], x1 = px[1];
             const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
-            v0 += x0 * k0 + x1 * k1;       // output depth 0 sees (mu=0, mu=1)
+            v0 += x0 * k0;                 // output depth 0 sees (mu=0, mu=1); one multiply-add each, in this order,
+            v0 += x1 * k1;                 // in EVERY implementation of conv1 (forward, reverse pass, K1c)
             v1 += x1 * k0;                 // output depth 1 sees (mu=1, pad)
           }
         }
@@ -596,7 +597,8 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 8))) vo
             const float* px = xin + ((c * TP + i + di) * XP + j + dj) * 2;
             const float x0 = px[0], x1 = px[1];
             const float k0 = w1[((di * 3 + dj) * 2 + 0) * F + f], k1 = w1[((di * 3 + dj) * 2 + 1) * F + f];
-            v0 += x0 * k0 + x1 * k1;
+            v0 += x0 * k0;                 // (the forward kernel's order: the pooling winners are ITS winners)
+            v0 += x1 * k1;
             v1 += x1 * k0;
           }
         }

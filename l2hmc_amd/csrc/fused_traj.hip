@@ -394,7 +394,8 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gau
               for (int dj = 0; dj < 3; ++dj) {
                 const f32x2 xx = px[a + di][bb + dj];
                 const f32x2 x0 = {xx[0], xx[0]}, x1 = {xx[1], xx[1]};
-                v0 += x0 * k0[di * 3 + dj] + x1 * k1[di * 3 + dj];
+                v0 += x0 * k0[di * 3 + dj];      // (conv3d_front.hip's order: three fused multiply-adds per tap)
+                v0 += x1 * k1[di * 3 + dj];
                 v1 += x1 * k0[di * 3 + dj];
               }
             }

@@ -33,7 +33,7 @@ def read(dirname, want=None):
             for row in csv.DictReader(fh):
                 if want and want not in row["Kernel_Name"]:
                     continue
-                if want == KERNEL and int(row["Grid_Size"]) != ROWS // 16 * 256:
+                if want == KERNEL and int(row["Grid_Size"]) not in (ROWS // 16 * 256, ROWS // 16 * 512):   # (4 or 8 waves per workgroup)
                     continue                      # only the benchmark-shaped launches (4096 rows)
                 acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     # median: a launch that overlaps another stream's work (an asynchronous copy, the side-stream all-reduce
