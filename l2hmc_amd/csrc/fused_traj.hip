@@ -723,7 +723,7 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gau
       } else {
         // Two waves share an image wave's columns.  The bits of the 4-wave forms are those of ONE chain of adds per
         // lane over both waves' tiles, then the cross-lane steps: the even wave hands its lane sum over, the odd wave
-        // continues the chain with its own four terms behind the barrier below (ld_terms) and does the rest.
+        // continues the chain with its own four terms behind the barrier below (ld_k, ld_s) and does the rest.
         if (wsub == 0) ldx[wimg * 64 + lane] = ld;
       }
       FT_ADD(5, t0);
