@@ -32,18 +32,17 @@ namespace l2hmc {
 
 // D = x_dim, H = hidden width, KA = width of each first-layer input (x_dim for GenericNet; the flattened conv
 // features for ConvNet3D), CONV = the two inputs go through the conv front-end first (8x8 lattice, F = 8).
-template <int D, int H, int KA = D, bool CONV = false, bool TAPE = false>
+template <int D, int H, int KA = D, bool CONV = false>
 struct FusedCfg {
-  // Waves per workgroup.  ConvNet3D plans run TWO waves per SIMD: their VALU conv stage is latency-bound at one
-  // (measured 0.987 -> 0.883 ms per step).  The GenericNet kernel used to be faster with one wave per SIMD (rounds 1-3:
-  // 1.655 against 1.745 ms); with the weight stream of round 4 (buffer loads, pinned interleave) two win -- one wave's
-  // epilogues and barriers lie under the other's matrix instructions: 1.431 -> 1.38 ms per step.  The TAPED forward of
-  // the training path stays at one wave per SIMD: its relu-gate words are laid out in the lane order the 4-wave reverse
-  // kernel reads (fused_train.hip).
-  // IMGW: waves the packed weight image is laid out for (pack_fused_kernel).  The 8-wave GenericNet instance reads the
-  // SAME 4-wave image as the taped forward and the 32-row form: two waves share a section (fused_common.h: load_frags).
+  // Waves per workgroup: TWO per SIMD in every instance.  ConvNet3D plans since round 2 (their VALU conv stage is
+  // latency-bound at one: 0.987 -> 0.883 ms per step).  The GenericNet kernel used to be faster with one wave per SIMD
+  // (rounds 1-3: 1.655 against 1.745 ms); with the weight stream of round 4 (buffer loads, pinned interleave) two win --
+  // one wave's epilogues and barriers lie under the other's matrix instructions: 1.431 -> 1.38 ms per step.
+  // IMGW: waves the packed weight image is laid out for (pack_fused_kernel).  The 8-wave GenericNet instances read the
+  // SAME 4-wave image as the 32-row form and the reverse kernel: two waves share a section (fused_common.h: load_frags),
+  // and the taped forward writes its relu-gate words in the 4-wave lane order the reverse kernel reads (fused_train.hip).
   static constexpr int IMGW = CONV ? 2 * kFWaves : kFWaves;
-  static constexpr int WAVES = (CONV || TAPE) ? IMGW : 2 * IMGW;
+  static constexpr int WAVES = 2 * kFWaves;
   static constexpr int RW = WAVES / IMGW;      // waves per image section
   static constexpr int THREADS = 64 * WAVES;   // wave w owns output columns [w*N/WAVES, (w+1)*N/WAVES)
   // threads per chain in the chain-local passes (force, kinetic energy, observables): their sums are part of the
@@ -140,8 +139,8 @@ extern "C" void l2hmc_debug_set_stagger(int cycles) { g_fused_stagger = cycles; 
 
 // TAPE: training instantiation (GenericNet plans) that also writes the per-call tape of train.hip
 template <int D, int H, int KA, bool CONV, bool TAPE = false>
-__global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gauge_traj_fused_kernel(FusedArgs p) {
-  using Cfg = FusedCfg<D, H, KA, CONV, TAPE>;
+__global__ __launch_bounds__((FusedCfg<D, H, KA, CONV>::THREADS)) void gauge_traj_fused_kernel(FusedArgs p) {
+  using Cfg = FusedCfg<D, H, KA, CONV>;
   constexpr int kFWaves = Cfg::WAVES, kFThreads = Cfg::THREADS, kTPC = Cfg::TPC;   // this instance's geometry
   constexpr int SX = Cfg::SX, SH = Cfg::SH, SA = Cfg::SA, NT1 = Cfg::NT1, NTH = Cfg::NTH;
   constexpr int RW = Cfg::RW, IMGW = Cfg::IMGW, NTI1 = Cfg::NTI1, NTIH = Cfg::NTIH;
@@ -583,7 +582,12 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gau
         }
         *reinterpret_cast<f32x4*>(h1 + r * SH + c0) = hv;
       }
-      if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 0) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
+      if constexpr (TAPE) {
+        // one 32-bit word per lane of the 4-wave image wave (the reverse kernel's layout); two waves of a section write its halves
+        const size_t word = ((size_t)(callidx * 2 + 0) * gridDim.x + blockIdx.x) * (64 * IMGW) + wimg * 64 + lane;
+        if constexpr (RW == 1) tp.gate[word] = gmask;
+        else reinterpret_cast<unsigned short*>(tp.gate)[word * 2 + wsub] = (unsigned short)gmask;
+      }
       FT_ADD(3, t0);
     }
     {
@@ -617,7 +621,12 @@ __global__ __launch_bounds__((FusedCfg<D, H, KA, CONV, TAPE>::THREADS)) void gau
         }
         *reinterpret_cast<f32x4*>(h2 + r * SH + c0) = hv;
       }
-      if constexpr (TAPE) tp.gate[((size_t)(callidx * 2 + 1) * gridDim.x + blockIdx.x) * kFThreads + tid] = gmask;
+      if constexpr (TAPE) {
+        // one 32-bit word per lane of the 4-wave image wave (the reverse kernel's layout); two waves of a section write its halves
+        const size_t word = ((size_t)(callidx * 2 + 1) * gridDim.x + blockIdx.x) * (64 * IMGW) + wimg * 64 + lane;
+        if constexpr (RW == 1) tp.gate[word] = gmask;
+        else reinterpret_cast<unsigned short*>(tp.gate)[word * 2 + wsub] = (unsigned short)gmask;
+      }
       FT_ADD(4, t0);
     }
     {
@@ -1009,11 +1018,10 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
                             const FusedTape* tape_v) {
   const bool conv = (p->flags & L2HMC_PLAN_CONV3D) != 0;
   using CfgG = FusedCfg<128, 512, 128, false>;
-  using CfgGT = FusedCfg<128, 512, 128, false, true>;          // (taped: one wave per image wave)
   using CfgC = FusedCfg<128, 256, 64, true>;
   static DeviceOnce attr_once;
   const bool tape = tape_x && tape_v;
-  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : tape ? CfgGT::LDS_FLOATS : CfgG::LDS_FLOATS);
+  const size_t lds = sizeof(float) * (conv ? CfgC::LDS_FLOATS : CfgG::LDS_FLOATS);
   if (attr_once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1045,7 +1053,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
     if (tape_once.pending()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 512, 128, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(float) * CfgGT::LDS_FLOATS)) != hipSuccess ||
+                              (int)(sizeof(float) * CfgG::LDS_FLOATS)) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(&gauge_traj_fused_kernel<128, 256, 64, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(float) * CfgC::LDS_FLOATS)) != hipSuccess) {
@@ -1072,7 +1080,7 @@ int launch_fused_trajectory(const l2hmc_gauge_plan* p, float beta, int step_begi
   else if (conv)
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 256, 64, true>), grid, dim3(CfgC::THREADS), lds, stream, a);
   else if (tape)
-    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(CfgGT::THREADS), lds, stream, a);
+    hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false, true>), grid, dim3(CfgG::THREADS), lds, stream, a);
   else
     hipLaunchKernelGGL((gauge_traj_fused_kernel<128, 512, 128, false>), grid, dim3(CfgG::THREADS), lds, stream, a);
   prof_after(kProfFused, stream);
