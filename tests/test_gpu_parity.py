@@ -401,6 +401,36 @@ def test_stq_conv3d_matches_oracle(la, L, rows, regime):
     assert np.abs(To).max() > 1e-4
 
 
+@pytest.mark.parametrize("L", [8, 16])
+def test_stq_conv3d_with_inputs_that_are_not_16_byte_aligned(la, L):
+    """The compile-time front-end instances stage the chains with 16-byte loads; inputs carved out of a buffer at an odd
+    float offset must take the run-time form (launch_conv3d_front) and still match the oracle."""
+    rows, D = 5, 2 * L * L
+    xp, _ = H.conv_weights(L, L, regime="stress")
+    net = la.ConvNet3D('XNet', _input_shape=(rows, L, L, 2), links_shape=(L, L, 2), x_dim=D, factor=2.,
+                       spatial_size=L, num_hidden=2 * D, num_filters=L, filter_sizes=[(3, 3, 2), (2, 2, 2)],
+                       name_scope='position', data_format='channels_last')
+    net.load_state(xp)
+    rng = np.random.default_rng(11)
+    a, b = rng.standard_normal((rows, D)), rng.uniform(0, 6.3, (rows, D))
+    t = np.array([[np.cos(0.4), np.sin(0.4)]])
+
+    def odd(z):          # the same values at data_ptr % 16 == 4
+        buf = torch.empty(rows * D + 1, dtype=torch.float32, device="cuda")
+        v = buf[1:].view(rows, D)
+        v.copy_(torch.as_tensor(z, dtype=torch.float32))
+        assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+        return v
+
+    S, Tr, Q = net([odd(a), odd(b), t])
+    S2, T2, Q2 = net([a, b, t])                                # aligned: the compile-time instance
+    p32 = {k: v.astype(np.float32).astype(np.float64) for k, v in xp.items()}
+    f32 = lambda z: z.astype(np.float32).astype(np.float64)   # noqa: E731
+    So, To, Qo = onets.conv3d_net(p32, [f32(a), f32(b), np.tile(f32(t), (rows, 1))], (L, L, 2))
+    for got, ref in ((S, So), (Tr, To), (Q, Qo), (S2, So), (T2, To), (Q2, Qo)):
+        assert H.relerr(np_(got), ref) < TOL_OP
+
+
 @pytest.mark.parametrize("L,N,B,regime", [(8, 5, 37, "mild"), (8, 3, 16, "stress"), (16, 2, 6, "init")])
 def test_conv3d_dynamics_matches_oracle(la, L, N, B, regime):
     eps, beta, D = 0.2, 2.0, 2 * L * L
