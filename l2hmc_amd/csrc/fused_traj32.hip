@@ -24,20 +24,31 @@ namespace l2hmc {
 namespace {
 constexpr int kD = 128, kH = 512;
 constexpr int kR32 = 32, kG32 = 2;                         // rows per workgroup, row groups of 16
-constexpr int kW32 = 4, kT32 = 256;                        // waves, threads (one wave per SIMD, as the 16-row form)
+// Two waves per SIMD since round 4 (fused_traj.hip: FusedCfg has the story): 8 waves read the 4-wave image, two waves
+// sharing a section; the chain-local passes and the fixed-order reductions stay on the first 256 threads (their sums
+// are part of the result's bits).
+constexpr int kIW32 = 4;                                   // waves the packed image is laid out for
+constexpr int kW32 = 8, kT32 = 64 * kW32;                  // waves, threads
+constexpr int kRW32 = kW32 / kIW32;                        // waves per image section
+constexpr int kCT32 = 256;                                 // threads of the chain-local passes and reductions
 constexpr int kSX = kD + 8, kSH = kH + 8, kSP = kD / 2 + 4;
-constexpr int kNT1 = kH / (16 * kW32), kNTH = kD / (16 * kW32);      // 8 tiles per wave in layers 1 / 2, 2 per head
+constexpr int kNT1 = kH / (16 * kW32), kNTH = kD / (16 * kW32);      // 4 tiles per wave in layers 1 / 2, 1 per head
+constexpr int kNTI1 = kH / (16 * kIW32), kNTIH = kD / (16 * kIW32);  // ... 8 and 2 per image section
+static_assert(kRW32 == 2 && kNTH == 1, "a shared heads section is walked with one tile per head and wave");
 constexpr int kKC1 = 2 * kD / 16, kKC2 = kH / 16;
 constexpr size_t kP1 = (size_t)2 * kD * kH, kP2 = (size_t)kH * kH;
 constexpr int kNC = 4 * kH + 5 * kD;
 constexpr int kTPC = 16;                                   // threads per chain in the chain-local passes (two passes of 16 chains)
-constexpr int kLds32 = 3 * kR32 * kSX + kR32 * kSH + 2 * kNC + kR32 * kSP + 2 * kD + kW32 * kR32 + kR32 + 8 * kR32;
+constexpr int kLds32 = 3 * kR32 * kSX + kR32 * kSH + 2 * kNC + kR32 * kSP + 2 * kD + kIW32 * kR32 /*ldw*/ +
+                       kIW32 * kG32 * 64 /*ldx*/ + kR32 + 8 * kR32;
+static_assert(kLds32 * sizeof(float) <= 160 * 1024, "LDS of the 32-row form");
 
 // Half a block for both row groups (fused_common.h: mfma_half_stream): every weight fragment cur[t] feeds two MFMAs,
 // so one load goes behind every EIGHTH MFMA.  e-major per accumulator, as the 16-row form.
-template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0>
+template <int NT, int T0, int T1, int L0, int L1, bool LOAD, int NDS = 0, int NTI = NT, int TS = 1>
 __device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1, const f32x4 (&cur)[NT], f32x4 (&dst)[NT],
-                                                  f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const WSection& wp, int kc) {
+                                                  f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const WSection& wp, int kc,
+                                                  int toff = 0) {
   constexpr int G = T1 - T0, NLD = L1 - L0;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -48,7 +59,7 @@ __device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1
     }
   if constexpr (LOAD) {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NT + L0 + j));
+    for (int j = 0; j < NLD; ++j) dst[L0 + j] = lane_frag(wp, (unsigned)(kc * NTI + toff + (L0 + j) * TS));
   }
   if constexpr (NDS > 0) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);     // the next block's two A fragments first
   sched_mfma_load_pipeline<G, LOAD ? NLD : 0, 8>();
@@ -56,9 +67,11 @@ __device__ __forceinline__ void mfma_half_stream2(const f32x4 a0, const f32x4 a1
 
 // stream_layer (fused_common.h) for two row groups; ap = the lane's fragment address in row group 0, gstride = floats
 // between the groups' rows
-template <int NT, int NKC, int DEPTH>
+// NTI, TS, toff: the wave's tiles in a shared image section (fused_common.h: load_frags)
+template <int NT, int NKC, int DEPTH, int NTI = NT, int TS = 1>
 __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* __restrict__ wbase, const float* ap,
-                                              int gstride, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], bool rev = false) {
+                                              int gstride, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], bool rev = false,
+                                              int toff = 0) {
   const WSection wp = wsection(wbase);
   static_assert(DEPTH >= 2 && NKC >= DEPTH && NT >= 2, "ring depth / tile groups");
   constexpr int G = (NT + 1) / 2;
@@ -74,9 +87,9 @@ __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* 
     for (int s = 0; s < DEPTH; ++s) {
       const int kn = km(kc + s + 1);
       const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
-      mfma_half_stream2<NT, 0, G, G, NT, true, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
-                                               km(kc + s + DEPTH - 1));
-      mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(kc + s + DEPTH));
+      mfma_half_stream2<NT, 0, G, G, NT, true, 2, NTI, TS>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
+                                                        km(kc + s + DEPTH - 1), toff);
+      mfma_half_stream2<NT, G, NT, 0, G, true, 0, NTI, TS>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(kc + s + DEPTH), toff);
       a0 = a1;
       c0 = c1;
     }
@@ -87,11 +100,12 @@ __device__ __forceinline__ void stream_layer2(BRing<NT, DEPTH>& R, const float* 
     const int kn = km(k + 1 < NKC ? k + 1 : NKC - 1);
     const f32x4 a1 = af(kn, 0), c1 = af(kn, 1);
     if (k + DEPTH - 1 < NKC)
-      mfma_half_stream2<NT, 0, G, G, NT, true, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, km(k + DEPTH - 1));
+      mfma_half_stream2<NT, 0, G, G, NT, true, 2, NTI, TS>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp,
+                                                        km(k + DEPTH - 1), toff);
     else
       mfma_half_stream2<NT, 0, G, G, NT, false, 2>(a0, c0, R.b[s], R.b[(s + DEPTH - 1) % DEPTH], acc0, acc1, wp, 0);
     if (k + DEPTH < NKC)
-      mfma_half_stream2<NT, G, NT, 0, G, true>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(k + DEPTH));
+      mfma_half_stream2<NT, G, NT, 0, G, true, 0, NTI, TS>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, km(k + DEPTH), toff);
     else
       mfma_half_stream2<NT, G, NT, 0, G, false>(a0, c0, R.b[s], R.b[s], acc0, acc1, wp, 0);
     a0 = a1;
@@ -112,8 +126,9 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
   float* cv = cx + kNC;
   float* sp = cv + kNC;                    // [32][SP] sin P
   float* skm = sp + ROWS * SP;             // [2][D] masks of this step: forward row, backward row
-  float* ldw = skm + 2 * D;                // [waves][32] log-det partial sums per wave
-  int* sdir = reinterpret_cast<int*>(ldw + kW32 * ROWS);   // [32]
+  float* ldw = skm + 2 * D;                // [image waves][32] log-det partial sums per image wave
+  float* ldx = ldw + kIW32 * ROWS;         // [image waves][2 row groups][64] lane sums an even wave hands to its odd partner
+  int* sdir = reinterpret_cast<int*>(ldx + kIW32 * kG32 * 64);   // [32]
   float* stp = reinterpret_cast<float*>(sdir + ROWS);      // step mode: coin[32] u[32] p_row[32] obs[32][4]
 
   const int tid = threadIdx.x;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
     else if (tid < nrow) d = p.dir ? p.dir[row0 + tid] : (p.dir_split > 0 && row0 + tid >= p.dir_split) ? 1 : 0;
     sdir[tid] = d;
   }
-  if (tid < kW32 * ROWS) ldw[tid] = 0.f;
+  if (tid < kIW32 * ROWS) ldw[tid] = 0.f;
   __syncthreads();
 
   // direction of the rows this lane owns in its C fragments: row 16 g + r
@@ -204,7 +219,10 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
 
   // ---- chain-local passes: 16 consecutive threads per chain, two passes of 16 chains (chain = 16 h + tid / 16);
   //      the terms of a chain are strided by 16 and summed by a butterfly over 16 lanes, as in the 16-row form
-  const int fc0 = tid / kTPC, fl = tid % kTPC;
+  // (the threads beyond 256 walk empty loops there and take part in the barriers only)
+  const bool own = tid < kCT32;
+  const int fc0 = own ? tid / kTPC : 0, fl = tid % kTPC;
+  const int sites_l = own ? sites : 0, D_l = own ? D : 0;
   auto chain_sum = [&](float v) {
 #pragma unroll
     for (int off = kTPC / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       const int fc = 16 * h + fc0;
       const float* xc = xs + fc * SX;
       float a = 0.f;
-      for (int s = fl; s < sites; s += kTPC) {
+      for (int s = fl; s < sites_l; s += kTPC) {
         const int i = s >> xsh, j = s & (X - 1);
         const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
         const float P = xc[2 * s] - xc[2 * s + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       const int fc = 16 * h + fc0;
       float* gc = gs + fc * SX;
       const float* spc = sp + fc * SP;
-      for (int s = fl; s < sites; s += kTPC) {
+      for (int s = fl; s < sites_l; s += kTPC) {
         const int i = s >> xsh, j = s & (X - 1);
         const int jm = (j == 0) ? X - 1 : j - 1, im = (i == 0) ? T - 1 : i - 1;
         const float sP = spc[s];
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
     for (int h = 0; h < kG32; ++h) {
       const float* vc = vs + (16 * h + fc0) * SX;
       float k = 0.f;
-      for (int d = fl; d < D; d += kTPC) k += vc[d] * vc[d];
+      for (int d = fl; d < D_l; d += kTPC) k += vc[d] * vc[d];
       kin[h] = 0.5f * chain_sum(k);
     }
   };
@@ -270,10 +288,14 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
     const float* pk = net.packed;
     const bool zig = (callidx & 1) != 0;   // layers 2 and 3 alternate their direction per call (fused_common.h)
     const int wv = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: the weight loads' base stays in SGPRs
-    const float* wp1 = pk + (size_t)wv * kKC1 * NT1 * 256;
-    const float* wp2 = pk + kP1 + (size_t)wv * kKC2 * NT1 * 256;
-    const float* wph = pk + kP1 + kP2 + (size_t)wv * kKC2 * 3 * NTH * 256;
-    constexpr int DP1 = 3, DP2 = 3, DPH = 4;
+    const int wimg = wv / kRW32, wsub = wv - wimg * kRW32;    // image section, and this wave's share of it
+    const float* wp1 = pk + (size_t)wimg * kKC1 * kNTI1 * 256;
+    const float* wp2 = pk + kP1 + (size_t)wimg * kKC2 * kNTI1 * 256;
+    const float* wph = pk + kP1 + kP2 + (size_t)wimg * kKC2 * 3 * kNTIH * 256;
+    const int to1 = wsub * NT1, toh = wsub * NTH;              // first tile of this wave in a chunk of the section
+    constexpr int TSH = kNTIH;                                 // tile stride of a wave's heads fragments
+    float ld_s[kG32][4];                                       // the odd wave's log-det terms (the mask factor is re-read)
+    constexpr int DP1 = 2, DP2 = 3, DPH = 3;   // (ring depths; with two waves per SIMD they no longer matter: fused_traj.hip)
     BRing<NT1, DP2> R2;
     BRing<3 * NTH, DPH> R3;
     // ----- layer 1: two half-K streams (first input rows, then the second-input rows in gs)
@@ -287,19 +309,19 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
           for (int t = 0; t < NT1; ++t) acc[g][t] = keep_v[g][t];
       } else {
         BRing<NT1, DP1> RA;
-        const float* wpb = wp1 + (size_t)KH * NT1 * 256;
+        const float* wpb = wp1 + (size_t)KH * kNTI1 * 256;
         if (l1 == 4) {
 #pragma unroll
           for (int g = 0; g < kG32; ++g)
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc[g][t] = keep_x[g][t];
         } else {
-          ring_prime<NT1, DP1>(RA, wp1);
+          ring_prime<NT1, DP1, kNTI1>(RA, wp1, false, 0, to1);
 #pragma unroll
           for (int g = 0; g < kG32; ++g)
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          stream_layer2<NT1, KH, DP1>(RA, wp1, in1 + r * SX + q * 4, 16 * SX, acc[0], acc[1]);
+          stream_layer2<NT1, KH, DP1, kNTI1>(RA, wp1, in1 + r * SX + q * 4, 16 * SX, acc[0], acc[1], false, to1);
           if (l1 == 3) {
 #pragma unroll
             for (int g = 0; g < kG32; ++g)
@@ -307,8 +329,8 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
               for (int t = 0; t < NT1; ++t) keep_x[g][t] = acc[g][t];
           }
         }
-        ring_prime<NT1, DP1>(RA, wpb);
-        stream_layer2<NT1, KH, DP1>(RA, wpb, gs + r * SX + q * 4, 16 * SX, acc[0], acc[1]);
+        ring_prime<NT1, DP1, kNTI1>(RA, wpb, false, 0, to1);
+        stream_layer2<NT1, KH, DP1, kNTI1>(RA, wpb, gs + r * SX + q * 4, 16 * SX, acc[0], acc[1], false, to1);
         if (l1 == 1) {
 #pragma unroll
           for (int g = 0; g < kG32; ++g)
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
             for (int t = 0; t < NT1; ++t) keep_v[g][t] = acc[g][t];
         }
       }
-      ring_prime<NT1, DP2>(R2, wp2, zig, kKC2);      // layer-2 weights start flowing under the epilogue + barrier
+      ring_prime<NT1, DP2, kNTI1>(R2, wp2, zig, kKC2, to1);      // layer-2 weights start flowing under the epilogue + barrier
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
         const int c0 = (wave * NT1 + t) * 16 + q * 4;          // this lane: rows r and 16 + r, columns c0 .. c0 + 3
@@ -340,8 +362,8 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       for (int g = 0; g < kG32; ++g)
 #pragma unroll
         for (int t = 0; t < NT1; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      stream_layer2<NT1, kKC2, DP2>(R2, wp2, hh + r * SH + q * 4, 16 * SH, acc[0], acc[1], zig);
-      ring_prime<3 * NTH, DPH>(R3, wph, zig, kKC2);
+      stream_layer2<NT1, kKC2, DP2, kNTI1>(R2, wp2, hh + r * SH + q * 4, 16 * SH, acc[0], acc[1], zig, to1);
+      ring_prime<3 * NTH, DPH, 3 * kNTIH, TSH>(R3, wph, zig, kKC2, toh);
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < NT1; ++t) {
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       for (int g = 0; g < kG32; ++g)
 #pragma unroll
         for (int t = 0; t < 3 * NTH; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      stream_layer2<3 * NTH, kKC2, DPH>(R3, wph, hh + r * SH + q * 4, 16 * SH, acc[0], acc[1], zig);
+      stream_layer2<3 * NTH, kKC2, DPH, 3 * kNTIH, TSH>(R3, wph, hh + r * SH + q * 4, 16 * SH, acc[0], acc[1], zig, toh);
       const float* bhd = cn + 4 * H;
       const float* es = bhd + 3 * D;
       const float* eq = es + D;
@@ -403,6 +425,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
               const float es_ = fast_exp(s);
               vn[e] = d ? es_ * (v[e] + kick) : v[e] * es_ - kick;
               ld += s;
+              ld_s[g][e] = s;
             }
             *reinterpret_cast<f32x4*>(vs + idx) = vn;
             if (prep_next_mask) {
@@ -426,19 +449,44 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
               const float upd = d ? es_ * (x[e] - drift) : x[e] * es_ + drift;
               xn[e] = keep * x[e] + (1.f - keep) * upd;
               ld += (1.f - keep) * s;
+              ld_s[g][e] = s;
               kx[e] = (1.f - keep) * xn[e];
             }
             *reinterpret_cast<f32x4*>(xs + idx) = xn;
             if (prep_next_mask) *reinterpret_cast<f32x4*>(gs + idx) = kx;
           }
         }
-        // the row's log-det share of this wave: lanes r, r + 16, r + 32, r + 48 (fixed order: bit-reproducible)
-        ld += __shfl_xor(ld, 16, 64);
-        ld += __shfl_xor(ld, 32, 64);
-        if (q == 0) ldw[wave * ROWS + 16 * g + r] += ld;
+        // The bits of the 4-wave form are those of ONE chain of adds per lane over both waves' head columns, then the
+        // cross-lane steps: the even wave hands its lane sum over, the odd wave continues the chain with its own four
+        // terms behind the barrier below (ld_k, ld_s; fused_traj.hip has the same hand-off) and does the rest.
+        if (wsub == 0) ldx[(wimg * kG32 + g) * 64 + lane] = ld;
       }
     }
     __syncthreads();
+    if (wsub == 1) {
+#pragma unroll
+      for (int g = 0; g < kG32; ++g) {
+        float ld = ldx[(wimg * kG32 + g) * 64 + lane];
+        const int d = dirl[g];
+        const int c0 = wave * (D / kW32) + q * 4;                        // (NTH = 1: the wave's one head tile)
+        const f32x4 mf = *reinterpret_cast<const f32x4*>(skm + c0);
+        const f32x4 mb = *reinterpret_cast<const f32x4*>(skm + D + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                    // the statements of the chain above, verbatim
+          const float s = ld_s[g][e];
+          if (mode == 1) {
+            ld += s;
+          } else {
+            const float keep = sub == 0 ? (d ? 1.f - mb[e] : mf[e]) : (d ? mb[e] : 1.f - mf[e]);
+            ld += (1.f - keep) * s;
+          }
+        }
+        // the row's log-det share of this image wave: lanes r, r + 16, r + 32, r + 48 (fixed order: bit-reproducible)
+        ld += __shfl_xor(ld, 16, 64);
+        ld += __shfl_xor(ld, 32, 64);
+        if (q == 0) ldw[wimg * ROWS + 16 * g + r] += ld;
+      }
+    }
   };
 
   // ---- leapfrog steps ----
@@ -473,13 +521,13 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
   force_pass(act1);
   kinetic_pass(kin1);
   if (STEPM) {
-    if (fl == 0) {
+    if (own && fl == 0) {
 #pragma unroll
       for (int h = 0; h < kG32; ++h) {
         const int fc = 16 * h + fc0;
         float sld = 0.f;
 #pragma unroll
-        for (int w = 0; w < kW32; ++w) sld += ldw[w * ROWS + fc];
+        for (int w = 0; w < kIW32; ++w) sld += ldw[w * ROWS + fc];
         const double dh = (double)p.beta * ((double)act0[h] - (double)act1[h]) + ((double)kin0[h] - (double)kin1[h]) +
                           (double)sld;
         spx[fc] = accept_from_delta(dh);
@@ -529,7 +577,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
     auto plaq_sums = [&](const float* xc, float& scos, float& sproj) {
       const float inv2pi = 0.15915494309189533577f;
       float a = 0.f, b = 0.f;
-      for (int st = fl; st < sites; st += kTPC) {
+      for (int st = fl; st < sites_l; st += kTPC) {
         const int i = st >> xsh, j = st & (X - 1);
         const int jp = (j + 1 == X) ? 0 : j + 1, ip = (i + 1 == T) ? 0 : i + 1;
         const float P = xc[2 * st] - xc[2 * st + 1] - xc[2 * (i * X + jp)] + xc[2 * (ip * X + j) + 1];
@@ -547,7 +595,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       if (p.step_both) {
         float a, b;
         plaq_sums(fc < ROWS / 2 ? gin + fc * SX : gout + (fc - ROWS / 2) * SX, a, b);
-        if (fl == 0) {
+        if (own && fl == 0) {
           if (fc < ROWS / 2) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; }
           else sobs[(fc - ROWS / 2) * 4 + 2] = b;
         }
@@ -555,7 +603,7 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
         float a, b, c_, d_;
         plaq_sums(gin + fc * SX, a, b);
         plaq_sums(gout + fc * SX, c_, d_);
-        if (fl == 0) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; sobs[fc * 4 + 2] = d_; }
+        if (own && fl == 0) { sobs[fc * 4 + 0] = a; sobs[fc * 4 + 1] = b; sobs[fc * 4 + 2] = d_; }
       }
     }
     __syncthreads();
@@ -589,25 +637,27 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
       __syncthreads();
       if (*last) {
         __threadfence();
-        float a0 = 0.f, a1 = 0.f;
-        for (int b = tid; b < (int)gridDim.x; b += kT32) {
+        float a0 = 0.f, a1 = 0.f;                         // (256 partial sums and their tree, whatever the thread count)
+        for (int b = tid; own && b < (int)gridDim.x; b += kCT32) {
           a0 += p.step_part[2 * b];
           a1 += p.step_part[2 * b + 1];
         }
         float* fin = vs;                                  // [2][256] scratch (vs is dead)
-        fin[tid] = a0;
-        fin[kT32 + tid] = a1;
+        if (own) {
+          fin[tid] = a0;
+          fin[kCT32 + tid] = a1;
+        }
         __syncthreads();
-        for (int st = kT32 / 2; st > 0; st >>= 1) {
+        for (int st = kCT32 / 2; st > 0; st >>= 1) {
           if (tid < st) {
             fin[tid] += fin[tid + st];
-            fin[kT32 + tid] += fin[kT32 + tid + st];
+            fin[kCT32 + tid] += fin[kCT32 + tid + st];
           }
           __syncthreads();
         }
         if (tid == 0) {
           p.step_sums[0] = p.step_sums_acc ? p.step_sums[0] + fin[0] : fin[0];
-          p.step_sums[1] = p.step_sums_acc ? p.step_sums[1] + fin[kT32] : fin[kT32];
+          p.step_sums[1] = p.step_sums_acc ? p.step_sums[1] + fin[kCT32] : fin[kCT32];
           p.step_sums[2] = (float)p.step_B;
           *reinterpret_cast<int*>(p.step_sums + 3) = 0;
         }
@@ -632,14 +682,14 @@ __global__ __launch_bounds__(kT32) void gauge_traj_fused32_kernel(FusedArgs p) {
     }
     return;
   }
-  if (fl == 0) {
+  if (own && fl == 0) {
 #pragma unroll
     for (int h = 0; h < kG32; ++h) {
       const int fc = 16 * h + fc0;
       if (fc < nrow) {
         float sld = 0.f;
 #pragma unroll
-        for (int w = 0; w < kW32; ++w) sld += ldw[w * ROWS + fc];
+        for (int w = 0; w < kIW32; ++w) sld += ldw[w * ROWS + fc];
         const int64_t rr = row0 + fc;
         if (p.logdet) p.logdet[rr] = p.logdet_accumulate ? p.logdet[rr] + sld : sld;
         if (p.p_accept) {
