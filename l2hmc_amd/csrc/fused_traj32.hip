@@ -3,9 +3,10 @@
 // With 16 rows per workgroup every weight fragment a wave loads feeds ONE v_mfma_f32_16x16x4_f32 per k, and the issue
 // cost of that load (about 19 cycles of the wave's single instruction stream per global_load_dwordx4) caps the product
 // loops at 0.83 of the matrix pipe (tools/mfma_stream_bench.hip: 38.1 cycles per MFMA against 32).  Here a workgroup
-// owns 32 rows = two row groups that share every fragment: 16 accumulator tiles per wave, one load per eight MFMAs,
-// 35.0-35.8 cycles per MFMA in the same bench (profiles/r03_mfma_stream_bench.txt).  It needs 32 rows per CU, i.e. more
-// than 4096 rows per GPU, so it takes the batches the 16-row form would need two or more rounds for.
+// owns 32 rows = two row groups that share every fragment: one load per eight MFMAs, 35.0-35.8 cycles per MFMA in the
+// same bench (profiles/r03_mfma_stream_bench.txt).  It needs 32 rows per CU, i.e. more than 4096 rows per GPU, so it
+// takes the batches the 16-row form would need two or more rounds for.  Round 4: buffer loads with the pinned
+// interleave (fused_common.h), then 8 waves per workgroup on the 4-wave image (8 accumulator tiles per wave).
 //
 // Same algorithm, same packed weight image, same arithmetic ORDER as fused_traj.hip
 // (l2hmc/dynamics/gauge_dynamics.py:261-313, :412-609; network/generic_net.py:129-146): a row's accumulators see
@@ -14,7 +15,7 @@
 // (tests/test_gpu_parity.py::test_subtile_and_32_row_forms_equal_16_row_form).
 //
 // LDS: x, v, force rows (3 x 32 x 136), ONE hidden buffer (32 x 520; the second layer's output overwrites its input
-// behind an extra barrier -- two buffers would need 218 KB), constants, masks, scratch: 151.7 KB.  GenericNet on the
+// behind an extra barrier -- two buffers would need 218 KB), constants, masks, scratch: 153.7 KB.  GenericNet on the
 // 8x8 lattice (D = 128, H = 512), sampling only (no tape, no ConvNet3D).
 #include "fused_common.h"
 #include "fused_args.h"
