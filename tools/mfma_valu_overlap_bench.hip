@@ -18,7 +18,8 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
   const float x = (float)threadIdx.x * s, y = 1.f + s;
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  if (role == 1) {
+  if (role == 7) __builtin_amdgcn_s_setprio(3);
+  if (role == 1 || role == 7) {
     for (int it = 0; it < iters; ++it)
 #pragma unroll
       for (int r = 0; r < 8; ++r)
@@ -89,7 +90,7 @@ void run(const char* name, float* out, unsigned long long* cyc) {
   for (int i = 0; i < wgs; ++i) { for (int w = 0; w < 4; ++w) ma += (double)h[i * 8 + w]; for (int w = 4; w < 8; ++w) mb += (double)h[i * 8 + w]; }
   ma /= wgs * 4; mb /= wgs * 4;
   auto per = [&](int role, double m) {
-    if (role == 1) printf("  MFMA wave: %.1f cycles per MFMA", m / (iters * 32.0));
+    if (role == 1 || role == 7) printf("  MFMA wave%s: %.1f cycles per MFMA", role == 7 ? " (s_setprio 3)" : "", m / (iters * 32.0));
     if (role == 2) printf("  VALU wave: %.2f cycles per v_pk_fma_f32", m / (iters * 256.0));
     if (role >= 3) printf("  mixed wave: %.1f cycles per (1 MFMA + 8 v_pk_fma_f32)", m / (iters * 32.0));
   };
@@ -103,6 +104,8 @@ int main() {
   run<1, 2>("MFMA wave + packed-fma wave on the same SIMD", out, cyc);
   run<1, 1>("two MFMA waves on the same SIMD", out, cyc);
   run<2, 2>("two packed-fma waves on the same SIMD", out, cyc);
+  run<7, 1>("two MFMA waves, the first at s_setprio 3", out, cyc);
+  run<7, 2>("MFMA wave at s_setprio 3 + packed-fma wave", out, cyc);
   run<3, 0>("one wave: 1 MFMA + 8 packed fma, repeated", out, cyc);
   run<3, 3>("two such waves on the same SIMD", out, cyc);
   run<4, 0>("one wave, accumulators in AGPRs", out, cyc);
