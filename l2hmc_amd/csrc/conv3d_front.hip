@@ -132,10 +132,12 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
     const int di = q >> 1, dj = q & 1;
     // ---- conv1 (VALU) and conv2 (matrix pipe), pipelined over groups of chains.  A group is as many chains as give
     // every wave ONE conv2 tile (16 x 16: one chain, 8 x 8: four); the conv2 MFMAs of group g and the conv1 arithmetic
-    // of group g + 1 are independent and sit in one basic block, so the matrix pipe works under the packed VALU
-    // instructions instead of after them.  (Per CU and two-input launch at 16 x 16 the matrix pipe has 16 k cycles of
-    // work and the VALU 12-16 k; the counters of the shipped kernel read 27 % / 31 % of the SIMD cycles -- the four
-    // workgroups of a CU still finish between 10 and 23 us, i.e. one after the other rather than side by side.)
+    // of group g + 1 are independent and share a phase between two barriers.  A wave still issues them one after the
+    // other -- on this part no VALU instruction issues under the wave's OWN matrix instruction, only under another
+    // wave's, at half rate (profiles/r04_mfma_valu_overlap_bench.txt) -- so what the phase split buys is that the
+    // products of one wave can run beside the conv1 arithmetic of the others.  (Per CU and two-input launch at 16 x 16
+    // the matrix pipe has 16 k cycles of work and the VALU 12-16 k; the counters of the shipped kernel read 27 % / 31 %
+    // of the SIMD cycles; the four workgroups of a CU finish between 10 and 23 us after a common start: oldest first.)
     // conv1 (3,3,2) + relu + pool (2,2,2): a thread owns a PAIR of filters, so every multiply-add is a v_pk_fma_f32,
     // and the 4 x 4 x 2 input patch under a pooling window is read once.
     // conv2 (2,2,[2]) + relu + pool: per chain a [T2 X2 positions] x [4 F] x [2 F] product.  v_mfma_f32_16x16x4_f32
